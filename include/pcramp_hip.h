@@ -1,0 +1,166 @@
+/*
+ * pcramp_hip.h -- C-ABI of the MI355X-native primer-pair x target evaluation path.
+ *
+ * The reference (LANL-Bioinformatics/PCRamp v0.3) has no plugin/FFI layer: its boundary for
+ * this path is a set of C++ member functions called from main.cpp / optimize.cpp.  Each entry
+ * point below replaces the reference call sites it cites (file:line under the reference tree)
+ * and is what a `pcramp` host driver binds instead of them.
+ *
+ * Conventions: C linkage, opaque handle, plain pointers + sizes, caller-owned buffers, `int`
+ * status (0 = ok, <0 = error; text via pcr_last_error(), thread-local).  No exceptions cross
+ * the ABI.  A handle owns one GPU and one HIP stream and is not thread-safe (the reference's
+ * equivalent rule: one NucCruc / SeqOverlap per OpenMP thread, main.cpp:533,702).
+ * There is NO CPU fallback: every compute entry point fails if no gfx950 device is usable.
+ */
+#ifndef PCRAMP_HIP_H
+#define PCRAMP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCR_OK               0
+#define PCR_ERR_ARG         -1
+#define PCR_ERR_DEVICE      -2   /* no usable GPU / HIP failure */
+#define PCR_ERR_STATE       -3   /* call order (e.g. amplify before select) */
+#define PCR_ERR_CAPACITY    -4   /* a fixed device buffer would overflow even after growth */
+#define PCR_ERR_RANGE       -5   /* reference `throw` conditions (e.g. Sequence::has_split out of bounds) */
+
+typedef struct pcr_ctx pcr_ctx;
+
+/* Reference `Word` (= __word<unsigned long,2>, word.h:690): 32 slots of 4-bit IUPAC codes,
+ * slot k (0 = 5' end) at bits (15 - k%16)*4 of w[k/16]; A=1 C=2 G=4 T=8, EOS=0 (base_table.h:11-28). */
+typedef struct { uint64_t w[2]; } pcr_word128;
+
+/* One trial assay: PCR::f / PCR::r (assay.h:117-118). */
+typedef struct { pcr_word128 f, r; } pcr_pair;
+
+typedef enum { PCR_SET_TARGET = 0, PCR_SET_BACKGROUND = 1 } pcr_set;
+
+/* The `Options` fields (pcramp.h:83-128) that Sequence::pack reads (sequence.cpp:92-96). */
+typedef struct {
+	uint32_t pack_max_degen;  /* opt.pack_max_degen, default 256 (pcramp.h:43) */
+	float pack_min_gc;        /* opt.pack_min_gc, default 0 = off (pcramp.h:45) */
+	float pack_max_gc;        /* opt.pack_max_gc, default 1 = off (pcramp.h:44) */
+} pcr_params;
+
+/* One entry of the per-iteration word DB (`MULTIMAP<Word, WordMatch>`, sequence.h:34-76). */
+typedef struct {
+	pcr_word128 word;
+	int32_t loc;       /* WordMatch::loc */
+	uint32_t index;    /* WordMatch::index (sequence index inside its set) */
+	uint32_t strand;   /* 1 = Seq_strand_plus, 2 = Seq_strand_minus (sequence.h:27-32) */
+	uint32_t pad;
+} pcr_entry;
+
+/* Arguments of the amplicon screen; mirrors what PCR::collect_candidates (pcr_assay.cpp:12-18)
+ * and PCR::find_target_match / compute_coverage (pcr_assay.cpp:544,271) take from `Options`. */
+typedef struct {
+	float collect_threshold;  /* m_threshold of collect_candidates: target_threshold (find_target_match,
+	                             pcr_assay.cpp:556) or target_threshold*search_multiplier (assay.h:407);
+	                             squared inside, as pcr_assay.cpp:31-32 */
+	float ident_threshold;    /* the sqrtf(f*r) >= threshold test (pcr_assay.cpp:574, :294) */
+	int32_t amp_min, amp_max; /* m_amplicon_range (pcramp.h:14-18) */
+	int32_t use_taq_mama;     /* opt.use_taq_mama (optimize.cpp:209) */
+} pcr_amplify_args;
+
+const char *pcr_last_error(void);
+
+/* Device index + an optional caller HIP stream (hipStream_t as void*, NULL = create one).
+ * Fails (returns NULL) when no gfx950 device is available. */
+pcr_ctx *pcr_create(int device, void *hip_stream, const pcr_params *params);
+void pcr_destroy(pcr_ctx *ctx);
+
+/* Replaces the host-resident `deque<Sequence>` (main.cpp:257-344 after parse_fasta):
+ * `packed4` holds the sequences' 4-bit codes, high nibble first (sequence.h:223-228);
+ * sequence i starts at byte byte_offsets[i] and has lengths[i] bases; weights[i] = Sequence::weight().
+ * Builds the HBM-resident bit-plane store, the window-validity mask (the degeneracy / GC /
+ * EOS filters of Sequence::pack, sequence.cpp:127-153) and the irregular word list (centred
+ * partial words at sequence ends and around EOS, sequence.cpp:155-179,198-263). */
+int pcr_load_sequences(pcr_ctx *ctx, pcr_set which, const uint8_t *packed4,
+	const uint64_t *byte_offsets, const uint64_t *lengths, const float *weights, uint32_t n);
+
+/* Sequence::active(bool) for every sequence of the set (main.cpp:1105-1120); active[i] != 0 = active. */
+int pcr_set_active(pcr_ctx *ctx, pcr_set which, const uint8_t *active);
+
+/* Sequence::split_sequence (sequence.h:228-241; main.cpp:1008-1017): write EOS at `pos`. */
+int pcr_split(pcr_ctx *ctx, pcr_set which, uint32_t seq, uint64_t pos);
+
+/* The per-iteration index build, main.cpp:579-615 / 644-691: for every ACTIVE sequence
+ * Sequence::pack (sequence.cpp:92) + select_words (select_words.cpp:8) with the trial assays
+ * `pairs`; the result (the set's word DB) stays on the device.  `threshold` is the
+ * select_words m_threshold (target_threshold*target_search_multiplier, main.cpp:669; not squared);
+ * `min_oligo_length` is the pack argument (opt.min_oligo_length(), x0.9 for backgrounds, main.cpp:595).
+ * n_entries_out (optional) receives the DB size. */
+int pcr_select_words(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_pairs,
+	int optimize_5, int optimize_3, float threshold, uint32_t min_oligo_length,
+	uint64_t *n_entries_out);
+
+/* Copy the current word DB to the host (parity tests; the reference's target_db). Returns the
+ * number of entries (may exceed cap; only cap are written) or <0. */
+int64_t pcr_get_entries(pcr_ctx *ctx, pcr_set which, pcr_entry *out, uint64_t cap);
+
+/* The amplicon screen for a batch of pairs against every sequence of the set:
+ * PCR::collect_candidates + update_identity + the sqrtf(f*r) test, i.e. PCR::find_target_match
+ * (pcr_assay.cpp:544-578) and PCR::compute_coverage (pcr_assay.cpp:271-302) in one pass.
+ *   bits      : n_pairs x pcr_bitset_words(ctx,which) u64 words, bit (i%64) of word i/64 = sequence i
+ *               amplified by the pair (BitSet, bitset.h:7).  May be NULL.
+ *   bits_fr   : same shape, amplified through {F(+),R(-)} (pcr_assay.cpp:39-45).  May be NULL.
+ *   bits_rf   : same shape, amplified through {R(+),F(-)} (pcr_assay.cpp:52-58).  May be NULL.
+ *   coverage  : n_pairs floats = compute_coverage's return value (double sum in the reference's
+ *               amplicon order, then rounded to float).  May be NULL. */
+int pcr_amplify(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_pairs,
+	const pcr_amplify_args *args, uint64_t *bits, uint64_t *bits_fr, uint64_t *bits_rf,
+	float *coverage);
+
+/* Same screen, asynchronous on the handle's stream, results left in DEVICE memory
+ * (d_bits_fr / d_bits_rf: n_pairs x words each, caller-allocated, e.g. a torch tensor that is
+ * then all-gathered over RCCL).  No host synchronisation. */
+int pcr_amplify_device(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_pairs,
+	const pcr_amplify_args *args, uint64_t *d_bits_fr, uint64_t *d_bits_rf);
+
+/* compute_coverage's weight sum (pcr_assay.cpp:280-301) from gathered orientation bitsets:
+ * ascending index over bits_fr, then ascending index over bits_rf & ~bits_fr, accumulated in
+ * double; n = number of sequences, weights[n].  Pure host arithmetic (no device needed). */
+float pcr_coverage_from_bits(const uint64_t *bits_fr, const uint64_t *bits_rf,
+	const float *weights, uint64_t n);
+
+/* weighted_coverage (main.cpp:1402-1418): ascending-index double sum of weights over set bits. */
+float pcr_weighted_coverage(const uint64_t *bits, const float *weights, uint64_t n);
+
+uint32_t pcr_num_sequences(pcr_ctx *ctx, pcr_set which);
+uint64_t pcr_bitset_words(pcr_ctx *ctx, pcr_set which);   /* ceil(n/64) */
+
+/* Measurement hooks (bench.py): when enabled, the dominant kernel of pcr_select_words (the
+ * oligo x window match scan) is bracketed by HIP events on the handle's stream.
+ * pcr_profile_read: total milliseconds and number of launches since the last reset. */
+int pcr_profile_enable(pcr_ctx *ctx, int on);
+int pcr_profile_read(pcr_ctx *ctx, double *scan_ms, uint64_t *scan_launches, int reset);
+
+/* Blocks until the handle's stream is idle. */
+int pcr_synchronize(pcr_ctx *ctx);
+
+
+/* ---- Host-only helpers (pure CPU arithmetic of the host half of the index build; usable
+ * without a GPU; exercised by the `not gpu` tests). */
+
+/* The irregular words of one sequence (Sequence::pack's partial / EOS-adjacent emissions,
+ * sequence.cpp:155-179,198-263) whose size counter is >= min_oligo_length.  Returns the count. */
+int64_t pcr_host_irregular_words(const uint8_t *packed4, uint64_t len, const pcr_params *params,
+	uint32_t min_oligo_length, pcr_entry *out, uint64_t cap);
+
+/* valid_out[p] (p < len) = 1 iff the 32-base window starting at p is a regular window that
+ * Sequence::pack emits under `params` (all 32 bases non-EOS; GC and degeneracy filters pass). */
+int pcr_host_window_valid(const uint8_t *packed4, uint64_t len, const pcr_params *params, uint8_t *valid_out);
+
+/* select_words' candidate list (select_words.cpp:22-85): oligo words incl. 5'/3' slot shifts and
+ * their floors unsigned(size*threshold).  Returns the count (may exceed cap). */
+int64_t pcr_host_candidates(const pcr_pair *pairs, uint32_t n_pairs, int optimize_5, int optimize_3,
+	float threshold, pcr_word128 *words_out, uint32_t *floors_out, uint64_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCRAMP_HIP_H */

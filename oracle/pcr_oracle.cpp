@@ -1,0 +1,635 @@
+// TEST INFRASTRUCTURE ONLY -- see pcr_oracle.h.  Plain scalar C++; no SIMD, no threads.
+// Every block cites the reference (LANL-Bioinformatics/PCRamp v0.3) file:line it restates.
+#include "pcr_oracle.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <set>
+#include <string>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+namespace {
+
+enum { EOS = 0, BA = 1, BC = 2, BG = 4, BT = 8 };
+enum { PLUS = 1, MINUS = 2 };
+
+// ------------------------------------------------------------------------------------ Word
+// 32 slots, one IUPAC nibble each; slot 0 is the 5' end (word.cpp:11-16).
+struct W {
+	uint64_t b[2];
+	W() { b[0] = b[1] = 0; }
+	bool operator==(const W &r) const { return b[0] == r.b[0] && b[1] == r.b[1]; }
+	bool operator<(const W &r) const { return (b[0] != r.b[0]) ? (b[0] < r.b[0]) : (b[1] < r.b[1]); } // word.h:197
+	unsigned get(int k) const { return (unsigned)(b[k >> 4] >> ((15 - (k & 15))*4)) & 0xF; }       // word.h:290
+	void set(unsigned v, int k) {                                                                  // word.h:307
+		const int sh = (15 - (k & 15))*4;
+		b[k >> 4] = (b[k >> 4] & ~(uint64_t(0xF) << sh)) | (uint64_t(v) << sh);
+	}
+	int start() const { for(int k = 0;k < 32;++k){ if(get(k)) return k; } return 32; }            // word.h:256
+	int stop() const { for(int k = 31;k >= 0;--k){ if(get(k)) return k; } return -1; }            // word.h:273
+	unsigned size() const { unsigned n = 0; for(int k = 0;k < 32;++k){ n += (get(k) != 0); } return n; } // word.cpp:199
+	void shift_left() { b[0] = (b[0] << 4) | (b[1] >> 60); b[1] <<= 4; }                          // word.cpp:215
+	void shift_right() { b[1] = (b[1] >> 4) | (b[0] << 60); b[0] >>= 4; }                         // word.cpp:224
+	void push_back(unsigned v) {                                                                   // word.cpp:31-48
+		const int last = stop() + 1;
+		if(last < 32){ set(v, last); return; }
+		shift_left();
+		b[1] |= v;
+	}
+	double degeneracy() const {                                                                    // word.h:97-138
+		double r = 1.0;
+		for(int k = 0;k < 32;++k){
+			const unsigned d = __builtin_popcount(get(k));
+			if(d){ r *= d; }
+		}
+		return r;
+	}
+	W complement() const {                                                                         // word.h:140-183
+		W r;
+		const int first = start(), last = stop();
+		int dst = 0;
+		for(int src = last;src >= first;--src, ++dst){
+			const unsigned v = get(src);
+			unsigned c = 0;
+			if(v & BA) c |= BT;
+			if(v & BT) c |= BA;
+			if(v & BG) c |= BC;
+			if(v & BC) c |= BG;
+			r.set(c, dst);
+		}
+		return r;
+	}
+	void center() {                                                                                // word.h:392-418
+		int left = start();
+		int right = stop();
+		if(left > right) return;
+		right = 32 - right;
+		const int delta = (right - left)/2;   // C++ truncation toward zero
+		if(delta > 0){ for(int i = 0;i < delta;++i) shift_right(); }
+		else{ for(int i = 0;i > delta;--i) shift_left(); }
+	}
+};
+
+// # of slots whose base sets intersect (word.cpp:68-154).
+inline unsigned match_count(const W &x, const W &y)
+{
+	unsigned n = 0;
+	for(int h = 0;h < 2;++h){
+		uint64_t a = x.b[h] & y.b[h];
+		a = (a | (a >> 1) | (a >> 2) | (a >> 3)) & 0x1111111111111111ULL;
+		n += (unsigned)__builtin_popcountll(a);
+	}
+	return n;
+}
+
+inline unsigned base_bits(char c, bool &ok)                                                        // base_table.h:30-76
+{
+	ok = true;
+	switch(c){
+		case 'A': case 'a': return 1;
+		case 'C': case 'c': return 2;
+		case 'G': case 'g': return 4;
+		case 'T': case 't': case 'U': case 'u': return 8;
+		case 'M': case 'm': return 1|2;
+		case 'R': case 'r': return 4|1;
+		case 'S': case 's': return 4|2;
+		case 'V': case 'v': return 4|2|1;
+		case 'W': case 'w': return 1|8;
+		case 'Y': case 'y': return 8|2;
+		case 'H': case 'h': return 1|2|8;
+		case 'K': case 'k': return 4|8;
+		case 'D': case 'd': return 4|1|8;
+		case 'B': case 'b': return 4|8|2;
+		case 'N': case 'n': case 'I': case 'i': case 'X': case 'x': return 15;
+		case '-': return 0;
+		default: ok = false; return 0;
+	}
+}
+
+inline bool is_degen(unsigned v) { return !(v == 1 || v == 2 || v == 4 || v == 8); }              // base_table.h:125-139
+
+// word.cpp:233-294.  Table 2 of Li et al., Genomics 83 (2004) 311-320; rows = template pair,
+// columns = primer pair, both ordered {CC,GC,AC,TC,CG,GG,AG,TG,CA,GA,AA,TA,CT,GT,AT,TT}.
+const float TAQ_MAMA[256] = {
+	1.000f, 0.968f, 0.947f, 1.034f, 0.547f, 0.253f, 0.230f, 0.359f, 0.606f, 0.282f, 0.372f, 0.347f, 0.957f, 0.382f, 0.399f, 0.687f,
+	0.989f, 1.000f, 1.023f, 1.000f, 0.420f, 0.662f, 0.445f, 0.367f, 0.870f, 0.512f, 0.492f, 0.508f, 0.372f, 1.000f, 0.492f, 0.714f,
+	1.011f, 1.000f, 1.000f, 1.000f, 0.459f, 0.277f, 0.570f, 0.343f, 0.927f, 0.362f, 0.590f, 0.542f, 0.439f, 0.488f, 0.978f, 0.662f,
+	1.000f, 0.907f, 1.000f, 1.000f, 0.382f, 0.234f, 0.228f, 0.542f, 0.763f, 0.309f, 0.410f, 0.473f, 0.426f, 0.347f, 0.423f, 0.947f,
+	0.590f, 0.334f, 0.445f, 0.323f, 1.000f, 0.978f, 0.927f, 0.989f, 0.907f, 0.645f, 0.525f, 0.455f, 0.927f, 0.408f, 0.408f, 0.707f,
+	0.327f, 0.595f, 0.319f, 0.396f, 0.947f, 1.000f, 0.978f, 0.989f, 0.405f, 0.861f, 0.681f, 0.512f, 0.410f, 0.968f, 0.452f, 0.714f,
+	0.410f, 0.420f, 0.590f, 0.311f, 1.023f, 1.000f, 1.000f, 1.000f, 0.488f, 0.898f, 0.907f, 0.566f, 0.442f, 0.449f, 0.989f, 0.707f,
+	0.423f, 0.343f, 0.305f, 0.585f, 1.034f, 0.879f, 0.927f, 1.000f, 0.473f, 0.720f, 0.547f, 0.957f, 0.459f, 0.374f, 0.459f, 1.023f,
+	1.023f, 0.429f, 0.473f, 0.477f, 1.023f, 0.466f, 0.420f, 0.477f, 1.000f, 0.978f, 0.907f, 0.978f, 0.907f, 0.380f, 0.525f, 0.669f,
+	0.442f, 1.046f, 0.455f, 0.470f, 0.432f, 1.058f, 0.481f, 0.485f, 0.917f, 1.000f, 1.023f, 1.023f, 0.336f, 0.968f, 0.534f, 0.639f,
+	0.617f, 0.452f, 1.011f, 0.439f, 0.492f, 0.504f, 0.978f, 0.462f, 0.989f, 0.947f, 1.000f, 0.978f, 0.405f, 0.405f, 0.888f, 0.606f,
+	0.601f, 0.377f, 0.377f, 1.046f, 0.500f, 0.399f, 0.408f, 1.034f, 0.978f, 0.720f, 0.870f, 1.000f, 0.402f, 0.313f, 0.651f, 0.927f,
+	0.978f, 0.462f, 0.466f, 0.488f, 0.420f, 0.239f, 0.225f, 0.336f, 0.504f, 0.269f, 0.319f, 0.656f, 1.000f, 0.835f, 0.907f, 1.034f,
+	0.429f, 1.011f, 0.473f, 0.477f, 0.340f, 0.413f, 0.357f, 0.354f, 0.352f, 0.538f, 0.413f, 0.794f, 0.927f, 1.000f, 1.058f, 1.000f,
+	0.595f, 0.492f, 0.968f, 0.485f, 0.367f, 0.282f, 0.388f, 0.439f, 0.413f, 0.309f, 0.566f, 0.917f, 0.957f, 0.957f, 1.000f, 0.989f,
+	0.590f, 0.380f, 0.410f, 0.968f, 0.364f, 0.223f, 0.230f, 0.416f, 0.321f, 0.239f, 0.301f, 0.645f, 0.978f, 0.714f, 0.947f, 1.000f
+};
+
+inline int taq_index(unsigned v)                                                                   // word.cpp:233-247
+{
+	switch(v){ case BC: return 0; case BG: return 1; case BA: return 2; case BT: return 3; }
+	return -1;
+}
+
+float taq_mama(unsigned p1, unsigned p2, unsigned t1, unsigned t2)                                  // word.cpp:249-294
+{
+	const int a = taq_index(p1), b = taq_index(p2), c = taq_index(t1), d = taq_index(t2);
+	if(a < 0 || b < 0 || c < 0 || d < 0) return 1.0f;
+	return std::min(1.0f, TAQ_MAMA[16*(4*d + c) + (4*b + a)]);
+}
+
+// ------------------------------------------------------------------------------------ Sequence
+struct Seq {
+	std::vector<uint8_t> buf;   // high nibble first (sequence.h:223-228)
+	uint64_t len = 0;
+	float weight = 1.0f;
+	bool active = true;
+	unsigned at(uint64_t i) const { const uint8_t v = buf[i >> 1]; return (i & 1) ? (v & 0xF) : (v >> 4); }
+	void split(uint64_t i) { uint8_t &v = buf[i >> 1]; v = (i & 1) ? (v & 0xF0) : (v & 0x0F); } // sequence.h:228-241
+};
+
+struct Entry { W w; int32_t loc; uint32_t index; uint32_t strand; };
+
+// Sequence::pack, sequence.cpp:92-267.  The streaming window, the size counter that ignores
+// EOS, the GC ring of the last 32 pushed nibbles, the centred partial words at both ends, the
+// trailing shift-left loop -- all kept step for step.
+void pack(const Seq &s, unsigned index, unsigned degen_thr, float min_gc, float max_gc,
+	unsigned min_len, std::vector<Entry> &db)
+{
+	W w;
+	size_t cws = 0;
+	const bool gc_filter = (min_gc > 0.0f) || (max_gc < 1.0f);
+	std::deque<uint8_t> gc;
+	unsigned num_gc = 0;
+	const float norm = 1.0f/32;
+	const size_t nbytes = s.buf.size();
+	int loc = 1;
+	size_t it = 0;
+
+	for(;it != nbytes;++loc){                                                    // :110
+		unsigned b;
+		if(loc % 2 == 1){ b = s.buf[it] >> 4; }
+		else{ b = s.buf[it] & 0xF; ++it; }
+		w.push_back(b);                                                           // :122
+		cws += (b != EOS);                                                        // :125
+		if(gc_filter){                                                            // :127-146
+			if(gc.size() == 32){ num_gc -= ((gc.front() & (BG|BC)) != 0); gc.pop_front(); }
+			gc.push_back((uint8_t)b);
+			num_gc += ((b & (BG|BC)) != 0);
+			const float frac = num_gc*norm;
+			if(frac < min_gc || frac > max_gc){ cws = std::min(cws, size_t(31)); continue; }
+		}
+		if(w.degeneracy() > degen_thr){ cws = std::min(cws, size_t(31)); continue; } // :149-153
+		if(cws < 32){                                                             // :155-179
+			if(cws >= min_len){
+				W t = w;
+				t.center();
+				db.push_back(Entry{t, loc - int(cws) - t.start(), index, PLUS});
+				t = t.complement();
+				t.center();
+				db.push_back(Entry{t, loc - 1 + t.start(), index, MINUS});
+			}
+		}
+		else{                                                                     // :181-194
+			db.push_back(Entry{w, int(loc - cws), index, PLUS});
+			db.push_back(Entry{w.complement(), loc - 1, index, MINUS});
+			--cws;
+		}
+	}
+
+	while(cws > 0){                                                               // :198-263
+		w.shift_left();
+		--cws;
+		if(gc_filter){
+			if(gc.size() == 32){ num_gc -= ((gc.front() & (BG|BC)) != 0); gc.pop_front(); }
+			const float frac = num_gc*norm;
+			if(frac < min_gc || frac > max_gc){ continue; }
+		}
+		if(w.degeneracy() > degen_thr){ continue; }
+		if(cws >= min_len){
+			W t = w;
+			t.center();
+			db.push_back(Entry{t, loc - 1 - int(cws) - t.start(), index, PLUS});
+			t = t.complement();
+			t.center();
+			db.push_back(Entry{t, loc - 2 + t.start(), index, MINUS});
+		}
+	}
+}
+
+// Sequence::has_split, sequence.cpp:304-330 (throws on an out-of-range request).
+bool has_split(const Seq &s, int loc, int len)
+{
+	if( ((int64_t)loc + len > (int64_t)s.len) || loc < 0 || len < 0 ){
+		throw "has_split: range is out of bounds";
+	}
+	for(int i = 0;i < len;++i){ if(s.at(loc + i) == EOS) return true; }
+	return false;
+}
+
+inline bool entry_key_less(const Entry &a, const Entry &b) { return a.w < b.w; }
+
+} // namespace
+
+// ------------------------------------------------------------------------------------ session
+struct orc_session {
+	std::vector<Seq> seq;
+	std::vector<Entry> db;        // global target_db, sorted by key (read_only_multimap.h:93)
+	std::vector<W> keys;          // keys(target_db) (pcramp.h:231-256)
+	orc_options opt;
+	std::string err;
+	orc_session() {
+		opt.target_threshold = 1.0f; opt.search_multiplier = 0.9f;
+		opt.amp_min = 80; opt.amp_max = 200; opt.use_taq_mama = 0;
+		opt.pack_max_degen = 256; opt.pack_min_gc = 0.0f; opt.pack_max_gc = 1.0f;
+		opt.min_primer = 18; opt.optimize_5 = 0; opt.optimize_3 = 0;
+	}
+};
+
+namespace {
+
+// select_words, select_words.cpp:8-139: per candidate oligo (and its 5'/3' slot shifts), the
+// arg-max-with-ties set of unique source words at or above unsigned(size*threshold); the union
+// of those keys brings all of their occurrences in this sequence.
+void select_words(std::vector<Entry> &dst, std::vector<Entry> &src, const std::vector<W> &oligos,
+	bool opt5, bool opt3, float threshold)
+{
+	if(src.empty() || oligos.empty()) return;
+	std::stable_sort(src.begin(), src.end(), entry_key_less);
+	std::vector<W> skeys;                                                         // keys(m_src)
+	for(const Entry &e : src){ if(skeys.empty() || !(skeys.back() == e.w)) skeys.push_back(e.w); }
+
+	std::vector<W> cand;
+	for(const W &o : oligos){                                                     // :25-75
+		cand.push_back(o);
+		if(opt5 || opt3){
+			const int cs = o.start(), ce = o.stop();
+			if(opt5 && cs > 0){ W t = o; for(int j = 0;j < cs;++j){ t.shift_left(); cand.push_back(t); } }
+			if(opt3 && ce < 31){ W t = o; for(int j = ce;j < 31;++j){ t.shift_right(); cand.push_back(t); } }
+		}
+	}
+
+	std::set<size_t> matched;
+	for(const W &c : cand){
+		unsigned best = (unsigned)(c.size()*threshold);                           // :83  (unsigned*float -> float -> unsigned)
+		std::vector<size_t> buf;
+		for(size_t j = 0;j < skeys.size();++j){                                   // :100-117
+			const unsigned n = match_count(c, skeys[j]);
+			if(n >= best){
+				if(best < n) buf.clear();
+				best = n;
+				buf.push_back(j);
+			}
+		}
+		matched.insert(buf.begin(), buf.end());
+	}
+	for(size_t k : matched){                                                      // :126-138
+		Entry probe; probe.w = skeys[k];
+		auto r = std::equal_range(src.begin(), src.end(), probe, entry_key_less);
+		dst.insert(dst.end(), r.first, r.second);
+	}
+}
+
+struct OligoMatch { int32_t loc; uint32_t index; uint32_t strand; uint32_t key; uint8_t o; };
+struct Amplicon { uint32_t index; float weight; uint32_t f, r; uint8_t orient; };
+
+// match_words, optimize.cpp:291-301
+void match_words(std::vector<uint32_t> &out, const W &o, const std::vector<W> &keys, float thr)
+{
+	const unsigned scaled = (unsigned)(o.size()*thr);
+	for(size_t k = 0;k < keys.size();++k){ if(match_count(o, keys[k]) >= scaled) out.push_back((uint32_t)k); }
+}
+
+// find_oligo_match, optimize.cpp:263-289
+void find_oligo_match(std::vector<OligoMatch> &out, const std::vector<uint32_t> &wm, uint8_t oligo,
+	uint32_t strand, const orc_session &s)
+{
+	for(uint32_t k : wm){
+		Entry probe; probe.w = s.keys[k];
+		auto r = std::equal_range(s.db.begin(), s.db.end(), probe, entry_key_less);
+		for(auto j = r.first;j != r.second;++j){
+			if(!(j->strand & strand)) continue;
+			if(!s.seq[j->index].active) continue;
+			out.push_back(OligoMatch{j->loc, j->index, j->strand, k, oligo});
+		}
+	}
+}
+
+inline int loc5(const OligoMatch &m, int start, int stop) { return (m.strand == PLUS) ? m.loc + start : m.loc - stop; }  // sequence.h:57-65
+inline int loc3(const OligoMatch &m, int start, int stop) { return (m.strand == PLUS) ? m.loc + stop : m.loc - start; }  // sequence.h:67-75
+
+// PCR::find_amplicon_match, pcr_assay.cpp:338-441
+void find_amplicon_match(std::vector<Amplicon> &amp, const std::vector<OligoMatch> &m, uint8_t plus_o,
+	uint8_t minus_o, const W &plus_w, const W &minus_w, const orc_session &s, int amp_min, int amp_max,
+	uint8_t orient)
+{
+	const int ps = plus_w.start(), pe = plus_w.stop(), ms = minus_w.start(), me = minus_w.stop();
+	for(size_t p = 0;p < m.size();++p){
+		if(m[p].o != plus_o) continue;
+		for(size_t q = p;q < m.size();++q){
+			if(m[p].index != m[q].index) break;
+			if(m[q].o != minus_o) continue;
+			if(loc3(m[p], ps, pe) >= loc5(m[q], ms, me)) continue;
+			int amp_start = loc5(m[p], ps, pe);
+			const int amp_stop = std::min(loc3(m[q], ms, me), int(s.seq[m[p].index].len - 1));
+			int amp_len = amp_stop - amp_start + 1;
+			if(amp_len < amp_min) continue;
+			if(amp_len > amp_max) break;
+			if(amp_start < 0){ amp_len += amp_start; amp_start = 0; }
+			if(has_split(s.seq[m[p].index], amp_start, amp_len)) break;
+			if(plus_o == 0) amp.push_back(Amplicon{m[p].index, s.seq[m[p].index].weight, m[p].key, m[q].key, orient});
+			else amp.push_back(Amplicon{m[p].index, s.seq[m[p].index].weight, m[q].key, m[p].key, orient});
+		}
+	}
+}
+
+inline bool om_less(const OligoMatch &a, const OligoMatch &b)                     // assay.h:48-61
+{
+	if(a.index != b.index) return a.index < b.index;
+	return a.loc < b.loc;
+}
+
+// PCR::collect_candidates, pcr_assay.cpp:12-69
+void collect_candidates(std::vector<Amplicon> &amp, std::map<uint32_t, float> &fi, std::map<uint32_t, float> &ri,
+	const W &F, const W &R, const orc_session &s, float thr, int amp_min, int amp_max)
+{
+	amp.clear();
+	std::vector<uint32_t> fm, rm;
+	match_words(fm, F, s.keys, thr*thr);                                          // :31-32
+	match_words(rm, R, s.keys, thr*thr);
+	std::vector<OligoMatch> om;
+	find_oligo_match(om, fm, 0, PLUS, s);
+	find_oligo_match(om, rm, 1, MINUS, s);
+	std::stable_sort(om.begin(), om.end(), om_less);
+	find_amplicon_match(amp, om, 0, 1, F, R, s, amp_min, amp_max, 1);
+	om.clear();
+	find_oligo_match(om, fm, 0, MINUS, s);
+	find_oligo_match(om, rm, 1, PLUS, s);
+	std::stable_sort(om.begin(), om.end(), om_less);
+	find_amplicon_match(amp, om, 1, 0, R, F, s, amp_min, amp_max, 2);
+	fi.clear(); ri.clear();
+	for(const Amplicon &a : amp){ fi[a.f] = 0.0f; ri[a.r] = 0.0f; }
+}
+
+// update_identity, optimize.cpp:209-261
+void update_identity(std::map<uint32_t, float> &ident, const W &w, const std::vector<W> &keys, bool use_taq)
+{
+	if(ident.empty()) return;
+	const unsigned len = w.size();
+	const float norm = 1.0/len;                                                   // double divide, rounded to float (:221)
+	for(auto &kv : ident){ kv.second = match_count(w, keys[kv.first])*norm; }
+	if(!use_taq) return;
+	const int last = w.stop(), pen = last - 1;
+	const unsigned p1 = w.get(pen), p2 = w.get(last);
+	if(!is_degen(p1) && !is_degen(p2)){
+		for(auto &kv : ident){
+			const W &k = keys[kv.first];
+			const unsigned t1 = k.get(pen), t2 = k.get(last);
+			if(!is_degen(t1) && !is_degen(t2)){ kv.second *= taq_mama(p1, p2, t1, t2); }
+		}
+	}
+}
+
+W load_word(const uint64_t *p) { W w; w.b[0] = p[0]; w.b[1] = p[1]; return w; }
+
+} // namespace
+
+extern "C" {
+
+unsigned orc_word_and(const uint64_t a[2], const uint64_t b[2]) { return match_count(load_word(a), load_word(b)); }
+unsigned orc_word_size(const uint64_t a[2]) { return load_word(a).size(); }
+int orc_word_start(const uint64_t a[2]) { return load_word(a).start(); }
+int orc_word_stop(const uint64_t a[2]) { return load_word(a).stop(); }
+double orc_word_degeneracy(const uint64_t a[2]) { return load_word(a).degeneracy(); }
+
+int orc_word_from_string(const char *s, uint64_t out[2])                          // word.h:234-249
+{
+	const size_t n = strlen(s);
+	if(n > 32) return -1;
+	W w;
+	for(size_t i = 0;i < n;++i){
+		bool ok;
+		const unsigned v = base_bits(s[i], ok);
+		if(!ok) return -1;
+		w.set(v, (int)i);
+	}
+	out[0] = w.b[0]; out[1] = w.b[1];
+	return 0;
+}
+
+void orc_word_center(uint64_t w[2]) { W x = load_word(w); x.center(); w[0] = x.b[0]; w[1] = x.b[1]; }
+void orc_word_complement(const uint64_t in[2], uint64_t out[2]) { W x = load_word(in).complement(); out[0] = x.b[0]; out[1] = x.b[1]; }
+void orc_word_shift_left(uint64_t w[2]) { W x = load_word(w); x.shift_left(); w[0] = x.b[0]; w[1] = x.b[1]; }
+void orc_word_shift_right(uint64_t w[2]) { W x = load_word(w); x.shift_right(); w[0] = x.b[0]; w[1] = x.b[1]; }
+
+// Word::begin / Word::next, word.h:525-647: an odometer over the IUPAC expansions.  The
+// reference walks bytes from the least-significant byte of buffer[0] upward, low nibble before
+// high nibble, i.e. slot order 15,14,...,0,31,30,...,16; within a slot A -> C -> G -> T (lowest
+// set bit first), skipping bases outside the slot's set.
+int orc_word_expand(const uint64_t in[2], uint64_t *out, int cap)
+{
+	const W src = load_word(in);
+	int order[32];
+	for(int i = 0;i < 16;++i){ order[i] = 15 - i; order[16 + i] = 31 - i; }
+	W it;
+	for(int k = 0;k < 32;++k){
+		const unsigned v = src.get(k);
+		if(v){ it.set(v & (0u - v), k); }   // lowest set bit
+	}
+	int n = 0;
+	while(true){
+		if(n < cap){ out[2*n] = it.b[0]; out[2*n + 1] = it.b[1]; }
+		++n;
+		bool advanced = false;
+		for(int oi = 0;oi < 32 && !advanced;++oi){
+			const int k = order[oi];
+			unsigned cur = it.get(k);
+			if(cur == EOS) continue;
+			const unsigned set = src.get(k);
+			bool wrapped = false;
+			do{
+				if(cur == BT){ cur = BA; wrapped = true; }
+				else{ cur <<= 1; }
+			} while(!(cur & set));
+			it.set(cur, k);
+			if(!wrapped) advanced = true;
+		}
+		if(!advanced) break;
+	}
+	return n;
+}
+
+float orc_taq_mama(unsigned p1, unsigned p2, unsigned t1, unsigned t2) { return taq_mama(p1, p2, t1, t2); }
+
+static bool seq_from_text(Seq &q, const char *seq)                                // sequence.cpp:11-39
+{
+	const size_t n = strlen(seq);
+	q.len = n;
+	q.buf.assign((n + 1)/2, 0);
+	for(size_t i = 0;i < n;++i){
+		bool ok;
+		const unsigned v = base_bits(seq[i], ok);
+		if(!ok) return false;
+		q.buf[i >> 1] |= (i & 1) ? v : (v << 4);
+	}
+	return true;
+}
+
+long orc_pack(const char *seq, unsigned index, unsigned degen_thr, float min_gc, float max_gc,
+	unsigned min_len, orc_entry *out, long cap)
+{
+	Seq q;
+	if(!seq_from_text(q, seq)) return -1;
+	std::vector<Entry> db;
+	pack(q, index, degen_thr, min_gc, max_gc, min_len, db);
+	std::stable_sort(db.begin(), db.end(), entry_key_less);
+	long n = 0;
+	for(const Entry &e : db){
+		if(n < cap){
+			out[n].w[0] = e.w.b[0]; out[n].w[1] = e.w.b[1];
+			out[n].loc = e.loc; out[n].index = e.index; out[n].strand = e.strand; out[n].pad = 0;
+		}
+		++n;
+	}
+	return n;
+}
+
+orc_session *orc_session_create(void) { return new orc_session(); }
+void orc_session_destroy(orc_session *s) { delete s; }
+const char *orc_session_error(orc_session *s) { return s->err.c_str(); }
+
+int orc_session_add_target(orc_session *s, const char *seq, float weight, int active)
+{
+	Seq q;
+	if(!seq_from_text(q, seq)){ s->err = "illegal base"; return -1; }
+	q.weight = weight; q.active = (active != 0);
+	s->seq.push_back(q);
+	return 0;
+}
+
+int orc_session_add_target_packed(orc_session *s, const uint8_t *packed, uint64_t len, float weight, int active)
+{
+	Seq q;
+	q.len = len;
+	q.buf.assign(packed, packed + (len + 1)/2);
+	q.weight = weight; q.active = (active != 0);
+	s->seq.push_back(q);
+	return 0;
+}
+
+int orc_session_set_active(orc_session *s, unsigned idx, int active)
+{
+	if(idx >= s->seq.size()) return -1;
+	s->seq[idx].active = (active != 0);
+	return 0;
+}
+
+int orc_session_split(orc_session *s, unsigned idx, unsigned pos)
+{
+	if(idx >= s->seq.size() || pos >= s->seq[idx].len) return -1;
+	s->seq[idx].split(pos);
+	return 0;
+}
+
+void orc_session_set_options(orc_session *s, const orc_options *o) { s->opt = *o; }
+
+long orc_session_select(orc_session *s, const uint64_t *pairs, unsigned n_pairs, float threshold, int min_len_override)
+{
+	std::vector<W> oligos;
+	for(unsigned i = 0;i < n_pairs;++i){ oligos.push_back(load_word(pairs + 4*i)); oligos.push_back(load_word(pairs + 4*i + 2)); }
+	const orc_options &o = s->opt;
+	const float thr = (threshold < 0.0f) ? o.target_threshold*o.search_multiplier : threshold;   // main.cpp:669
+	const unsigned min_len = (min_len_override >= 0) ? (unsigned)min_len_override : (unsigned)std::max(0, o.min_primer);
+	s->db.clear();
+	for(size_t i = 0;i < s->seq.size();++i){                                      // main.cpp:644-676
+		if(!s->seq[i].active) continue;
+		std::vector<Entry> local;
+		pack(s->seq[i], (unsigned)i, o.pack_max_degen, o.pack_min_gc, o.pack_max_gc, min_len, local);
+		select_words(s->db, local, oligos, o.optimize_5 != 0, o.optimize_3 != 0, thr);
+	}
+	std::stable_sort(s->db.begin(), s->db.end(), entry_key_less);                 // main.cpp:679
+	s->keys.clear();                                                              // main.cpp:691
+	for(const Entry &e : s->db){ if(s->keys.empty() || !(s->keys.back() == e.w)) s->keys.push_back(e.w); }
+	return (long)s->db.size();
+}
+
+long orc_session_db_entries(orc_session *s, orc_entry *out, long cap)
+{
+	long n = 0;
+	for(const Entry &e : s->db){
+		if(n < cap){
+			out[n].w[0] = e.w.b[0]; out[n].w[1] = e.w.b[1];
+			out[n].loc = e.loc; out[n].index = e.index; out[n].strand = e.strand; out[n].pad = 0;
+		}
+		++n;
+	}
+	return n;
+}
+
+int orc_session_target_match(orc_session *s, const uint64_t pair[4], unsigned char *bits_out, unsigned char *orient_out)
+{
+	try{
+		const W F = load_word(pair), R = load_word(pair + 2);
+		const size_t T = s->seq.size();
+		memset(bits_out, 0, T);
+		if(orient_out) memset(orient_out, 0, T);
+		std::vector<Amplicon> amp;
+		std::map<uint32_t, float> fi, ri;
+		collect_candidates(amp, fi, ri, F, R, *s, s->opt.target_threshold, s->opt.amp_min, s->opt.amp_max); // :554-557
+		if(amp.empty()) return 0;
+		update_identity(fi, F, s->keys, s->opt.use_taq_mama != 0);
+		update_identity(ri, R, s->keys, s->opt.use_taq_mama != 0);
+		for(const Amplicon &a : amp){                                             // :565-577
+			const float local = sqrtf(fi[a.f]*ri[a.r]);
+			if(local >= s->opt.target_threshold){
+				bits_out[a.index] = 1;
+				if(orient_out) orient_out[a.index] |= a.orient;
+			}
+		}
+		return 0;
+	}
+	catch(const char *e){ s->err = e; return -1; }
+}
+
+float orc_session_target_coverage(orc_session *s, const uint64_t pair[4])
+{
+	try{
+		const W F = load_word(pair), R = load_word(pair + 2);
+		std::vector<Amplicon> amp;
+		std::map<uint32_t, float> fi, ri;
+		collect_candidates(amp, fi, ri, F, R, *s, s->opt.target_threshold*s->opt.search_multiplier,
+			s->opt.amp_min, s->opt.amp_max);                                      // assay.h:405-408
+		update_identity(fi, F, s->keys, s->opt.use_taq_mama != 0);
+		update_identity(ri, R, s->keys, s->opt.use_taq_mama != 0);
+		if(amp.empty()) return 0;                                                 // pcr_assay.cpp:271-302
+		double ret = 0.0;
+		std::unordered_set<uint32_t> valid;
+		for(const Amplicon &a : amp){
+			const float local = sqrtf(fi[a.f]*ri[a.r]);
+			if(local >= s->opt.target_threshold && valid.find(a.index) == valid.end()){
+				valid.insert(a.index);
+				ret += a.weight;
+			}
+		}
+		return (float)ret;
+	}
+	catch(const char *e){ s->err = e; return -1.0f; }
+}
+
+float orc_weighted_coverage(orc_session *s, const unsigned char *bits)            // main.cpp:1402-1418
+{
+	double ret = 0.0;
+	for(size_t i = 0;i < s->seq.size();++i){ if(bits[i]) ret += s->seq[i].weight; }
+	return (float)ret;
+}
+
+} // extern "C"

@@ -1,0 +1,86 @@
+// TEST INFRASTRUCTURE ONLY -- the parity checker.  Never linked into, imported by or shipped
+// with the product (pcramp_amd/): only tests/, __graft_entry__.smoke() and bench.py's
+// cpu_baseline leg may load liboracle.so.
+//
+// A plain scalar C++ restatement of the reference's primer x target evaluation path
+// (LANL-Bioinformatics/PCRamp v0.3).  Each function cites the reference file:line it follows.
+// Pinned against the real reference (oracle/_ref/libpcramp_ref.so, built from /root/reference
+// by oracle/Makefile) and against the committed golden vectors in tests/golden/ -- see
+// tests/test_oracle_vs_reference.py and tests/test_oracle_golden.py.
+#ifndef PCR_ORACLE_H
+#define PCR_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+// Word layout == reference `Word` (word.cpp:11-16): slot k (0 = 5' end) is the nibble at bits
+// (15 - k%16)*4 of w[k/16]; A=1 C=2 G=4 T=8, IUPAC = OR, EOS = 0 (base_table.h:11-28).
+typedef struct { uint64_t w[2]; } orc_word;
+
+typedef struct {
+	uint64_t w[2];
+	int32_t loc;      // WordMatch::loc (sequence.h:40)
+	uint32_t index;   // sequence index
+	uint32_t strand;  // 1 = plus, 2 = minus (sequence.h:27-32)
+	uint32_t pad;
+} orc_entry;
+
+typedef struct {
+	float target_threshold;     // opt.target_threshold            (pcramp.h:40)
+	float search_multiplier;    // opt.target_search_multiplier    (pcramp.h:51)
+	int32_t amp_min, amp_max;   // opt.target_amplicon_range       (pcramp.h:14-15)
+	int32_t use_taq_mama;       // opt.use_taq_mama
+	uint32_t pack_max_degen;    // opt.pack_max_degen              (pcramp.h:43)
+	float pack_min_gc, pack_max_gc;
+	int32_t min_primer;         // opt.primer_range.first -> min_oligo_length()
+	int32_t optimize_5, optimize_3;
+} orc_options;
+
+// ---- Word primitives
+unsigned orc_word_and(const uint64_t a[2], const uint64_t b[2]);           // word.cpp:68-154
+unsigned orc_word_size(const uint64_t a[2]);                               // word.cpp:199-213
+int orc_word_start(const uint64_t a[2]);                                   // word.h:256
+int orc_word_stop(const uint64_t a[2]);                                    // word.h:273
+double orc_word_degeneracy(const uint64_t a[2]);                           // word.h:97
+int orc_word_from_string(const char *s, uint64_t out[2]);                  // word.h:234
+void orc_word_center(uint64_t w[2]);                                       // word.h:392
+void orc_word_complement(const uint64_t in[2], uint64_t out[2]);           // word.h:140
+void orc_word_shift_left(uint64_t w[2]);                                   // word.cpp:215
+void orc_word_shift_right(uint64_t w[2]);                                  // word.cpp:224
+int orc_word_expand(const uint64_t in[2], uint64_t *out, int cap);         // word.h:525-647
+float orc_taq_mama(unsigned p1, unsigned p2, unsigned t1, unsigned t2);    // word.cpp:249-294
+
+// ---- Sequence::pack (sequence.cpp:92-267).  '-' in `seq` = Base::EOS.
+long orc_pack(const char *seq, unsigned index, unsigned degen_thr, float min_gc, float max_gc,
+	unsigned min_len, orc_entry *out, long cap);
+
+// ---- session (select_words + amplicon screen)
+typedef struct orc_session orc_session;
+orc_session *orc_session_create(void);
+void orc_session_destroy(orc_session *s);
+const char *orc_session_error(orc_session *s);
+int orc_session_add_target(orc_session *s, const char *seq, float weight, int active);
+int orc_session_add_target_packed(orc_session *s, const uint8_t *packed, uint64_t len, float weight, int active);
+int orc_session_set_active(orc_session *s, unsigned idx, int active);
+int orc_session_split(orc_session *s, unsigned idx, unsigned pos);         // sequence.h:228
+void orc_session_set_options(orc_session *s, const orc_options *o);
+// main.cpp:644-691 (pack + select_words per active sequence, then sort/keys)
+long orc_session_select(orc_session *s, const uint64_t *pairs, unsigned n_pairs,
+	float threshold, int min_len_override);
+long orc_session_db_entries(orc_session *s, orc_entry *out, long cap);
+// PCR::find_target_match (pcr_assay.cpp:544-578).  bits_out[i] in {0,1}.  If orient_out != NULL
+// it receives, per target, bit0 = matched through {F(+),R(-)}, bit1 = through {R(+),F(-)}.
+int orc_session_target_match(orc_session *s, const uint64_t pair[4], unsigned char *bits_out,
+	unsigned char *orient_out);
+// optimize.cpp:61-74: collect (search threshold) + update_identity + compute_coverage.
+float orc_session_target_coverage(orc_session *s, const uint64_t pair[4]);
+// main.cpp:1402-1418
+float orc_weighted_coverage(orc_session *s, const unsigned char *bits);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,393 @@
+// TEST INFRASTRUCTURE ONLY -- never linked into, imported by, or shipped with the product.
+//
+// A thin C API around the *real* reference classes, compiled from the sources where they
+// lie under /root/reference (see oracle/Makefile, target `ref`).  Nothing from the reference
+// is copied here: this file only #includes its headers and calls its public functions, so
+// that
+//   (1) the CPU restatement in oracle/pcr_oracle.cpp can be pinned against the reference
+//       itself, and golden vectors can be generated (oracle/make_golden.py), and
+//   (2) bench.py can time the reference's own CPU path as `cpu_baseline.kind = "reference"`.
+//
+// Output: oracle/_ref/libpcramp_ref.so (git-ignored; travels to the GPU box like any built .so).
+//
+// Reference entry points exercised (file:line in /root/reference):
+//   Word::operator&            word.cpp:68      Word::size            word.cpp:199
+//   Word::complement/center    word.h:140,392   Word::begin/next      word.h:525,570
+//   taq_mama_correction        word.cpp:249     Sequence::pack        sequence.cpp:92
+//   select_words               select_words.cpp:8
+//   PCR::find_target_match     pcr_assay.cpp:544
+//   PCR::collect_target_candidates / update_target_candidates / compute_target_coverage
+//                              assay.h:401,436,454 (-> pcr_assay.cpp:12,271; optimize.cpp:209)
+//   Sequence::split_sequence   sequence.h:228
+//   SO::SeqOverlap             seq_overlap.h / seq_overlap.cpp:347
+//   NucCruc                    nuc_cruc.h:414-1450
+
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <deque>
+
+#include "assay.h"        // reference header (pulls pcramp.h, sequence.h, word.h, nuc_cruc.h)
+#include "seq_overlap.h"  // reference header
+
+using namespace std;
+
+// The reference declares this in main.cpp only; restated here (5 lines of bookkeeping, the
+// arithmetic lives in the reference objects we link).
+static inline void words_of(const Word &w, uint64_t out[2])
+{
+	unsigned char buf[16];
+	w.mpi_pack(buf);
+	memcpy(out, buf, 16);
+}
+
+static inline Word word_from(const uint64_t in[2])
+{
+	Word w;
+	unsigned char buf[16];
+	memcpy(buf, in, 16);
+	w.mpi_unpack(buf);
+	return w;
+}
+
+struct RefEntry
+{
+	uint64_t w[2];
+	int32_t loc;
+	uint32_t index;
+	uint32_t strand; // 1 = plus, 2 = minus
+	uint32_t pad;
+};
+
+struct RefSession
+{
+	deque<Sequence> target_seq;
+	MULTIMAP<Word, WordMatch> target_db;
+	vector<Word> target_keys;
+	Options opt;
+	string last_error;
+};
+
+extern "C" {
+
+// ---------------------------------------------------------------- Word primitives
+unsigned ref_word_and(const uint64_t a[2], const uint64_t b[2])
+{
+	return word_from(a) & word_from(b);
+}
+
+unsigned ref_word_size(const uint64_t a[2])
+{
+	return word_from(a).size();
+}
+
+int ref_word_start(const uint64_t a[2]) { return word_from(a).start(); }
+int ref_word_stop(const uint64_t a[2]) { return word_from(a).stop(); }
+double ref_word_degeneracy(const uint64_t a[2]) { return word_from(a).degeneracy(); }
+
+int ref_word_from_string(const char *s, uint64_t out[2])
+{
+	try{
+		Word w;
+		w = string(s);
+		words_of(w, out);
+		return 0;
+	}
+	catch(...){ return -1; }
+}
+
+void ref_word_center(uint64_t w[2])
+{
+	Word x = word_from(w);
+	x.center();
+	words_of(x, w);
+}
+
+void ref_word_complement(const uint64_t in[2], uint64_t out[2])
+{
+	words_of(word_from(in).complement(), out);
+}
+
+void ref_word_shift_left(uint64_t w[2])
+{
+	Word x = word_from(w);
+	x.shift_left();
+	words_of(x, w);
+}
+
+void ref_word_shift_right(uint64_t w[2])
+{
+	Word x = word_from(w);
+	x.shift_right();
+	words_of(x, w);
+}
+
+// Expansion order of a degenerate word (Word::begin / Word::next).  Returns the count.
+int ref_word_expand(const uint64_t in[2], uint64_t *out, int cap)
+{
+	const Word w = word_from(in);
+	Word it = w.begin();
+	int n = 0;
+	do{
+		if(n < cap){
+			words_of(it, out + 2*n);
+		}
+		++n;
+	} while( w.next(it) );
+	return n;
+}
+
+float ref_taq_mama(unsigned p1, unsigned p2, unsigned t1, unsigned t2)
+{
+	return taq_mama_correction( make_pair( (unsigned char)p1, (unsigned char)p2 ),
+		make_pair( (unsigned char)t1, (unsigned char)t2 ) );
+}
+
+// ---------------------------------------------------------------- Sequence::pack
+// `seq` is IUPAC text; '-' encodes Base::EOS (a split / multi-record pad).
+long ref_pack(const char *seq, unsigned index, unsigned degen_thr, float min_gc, float max_gc,
+	unsigned min_len, RefEntry *out, long cap)
+{
+	try{
+		Sequence s;
+		s = string(seq);
+		MULTIMAP<Word, WordMatch> db;
+		s.pack(db, index, degen_thr, min_gc, max_gc, min_len);
+		long n = 0;
+		if( !db.empty() ){
+			for(MULTIMAP<Word, WordMatch>::const_iterator i = db.begin();i != db.end();++i){
+				if(n < cap){
+					words_of(i->first, out[n].w);
+					out[n].loc = i->second.loc;
+					out[n].index = i->second.index;
+					out[n].strand = (uint32_t)i->second.s;
+					out[n].pad = 0;
+				}
+				++n;
+			}
+		}
+		return n;
+	}
+	catch(const char *e){ return -1; }
+	catch(...){ return -2; }
+}
+
+// ---------------------------------------------------------------- session: select_words + amplicon screen
+RefSession *ref_session_create()
+{
+	return new RefSession();
+}
+
+void ref_session_destroy(RefSession *s)
+{
+	delete s;
+}
+
+const char *ref_session_error(RefSession *s) { return s->last_error.c_str(); }
+
+int ref_session_add_target(RefSession *s, const char *seq, float weight, int active)
+{
+	try{
+		s->target_seq.push_back( Sequence() );
+		Sequence &r = s->target_seq.back();
+		r = string(seq);
+		r.weight(weight);
+		r.active(active != 0);
+		return 0;
+	}
+	catch(const char *e){ s->last_error = e; return -1; }
+	catch(...){ s->last_error = "unknown"; return -2; }
+}
+
+int ref_session_set_active(RefSession *s, unsigned idx, int active)
+{
+	if(idx >= s->target_seq.size()) return -1;
+	s->target_seq[idx].active(active != 0);
+	return 0;
+}
+
+int ref_session_split(RefSession *s, unsigned idx, unsigned pos)
+{
+	if(idx >= s->target_seq.size()) return -1;
+	if(pos >= s->target_seq[idx].length()) return -1;
+	s->target_seq[idx].split_sequence(pos);
+	return 0;
+}
+
+void ref_session_set_options(RefSession *s,
+	float target_threshold, float search_multiplier,
+	int amp_min, int amp_max, int use_taq_mama,
+	unsigned pack_max_degen, float pack_min_gc, float pack_max_gc,
+	int min_primer, int optimize_5, int optimize_3)
+{
+	Options &o = s->opt;
+	o.target_threshold = target_threshold;
+	o.target_search_multiplier = search_multiplier;
+	o.target_amplicon_range = make_pair(amp_min, amp_max);
+	o.use_taq_mama = (use_taq_mama != 0);
+	o.pack_max_degen = pack_max_degen;
+	o.pack_min_gc = pack_min_gc;
+	o.pack_max_gc = pack_max_gc;
+	o.primer_range.first = min_primer;
+	o.optimize_5 = (optimize_5 != 0);
+	o.optimize_3 = (optimize_3 != 0);
+}
+
+// The per-iteration word-DB build of main.cpp:644-691 with the given trial assays
+// (pairs = n x {F[2], R[2]} 64-bit words).  `threshold` < 0 selects the reference's own
+// target_threshold*target_search_multiplier (main.cpp:669); `min_len_override` >= 0 replaces
+// opt.min_oligo_length() (backgrounds use 0.9x, main.cpp:595).
+long ref_session_select(RefSession *s, const uint64_t *pairs, unsigned n_pairs,
+	float threshold, int min_len_override)
+{
+	try{
+		vector<PCR> trial(n_pairs);
+		for(unsigned i = 0;i < n_pairs;++i){
+			trial[i].oligo( FORWARD, word_from(pairs + 4*i) );
+			trial[i].oligo( REVERSE, word_from(pairs + 4*i + 2) );
+		}
+
+		const Options &opt = s->opt;
+		const float thr = (threshold < 0.0f) ?
+			opt.target_threshold*opt.target_search_multiplier : threshold;
+		const unsigned min_len = (min_len_override >= 0) ?
+			(unsigned)min_len_override : (unsigned)opt.min_oligo_length();
+
+		s->target_db = MULTIMAP<Word, WordMatch>();
+
+		const unsigned n = s->target_seq.size();
+		for(unsigned i = 0;i < n;++i){
+			if( !s->target_seq[i].active() ){
+				continue;
+			}
+			MULTIMAP<Word, WordMatch> local_db;
+			s->target_seq[i].pack(local_db, i, opt.pack_max_degen, opt.pack_min_gc,
+				opt.pack_max_gc, min_len);
+			select_words(s->target_db, local_db, trial, opt.optimize_5, opt.optimize_3, thr);
+		}
+		s->target_db.sort();
+		s->target_keys = keys(s->target_db);
+		return (long)s->target_db.size();
+	}
+	catch(const char *e){ s->last_error = e; return -1; }
+	catch(...){ s->last_error = "unknown"; return -2; }
+}
+
+long ref_session_db_entries(RefSession *s, RefEntry *out, long cap)
+{
+	long n = 0;
+	if( s->target_db.empty() ) return 0;
+	for(MULTIMAP<Word, WordMatch>::const_iterator i = s->target_db.begin();i != s->target_db.end();++i){
+		if(n < cap){
+			words_of(i->first, out[n].w);
+			out[n].loc = i->second.loc;
+			out[n].index = i->second.index;
+			out[n].strand = (uint32_t)i->second.s;
+			out[n].pad = 0;
+		}
+		++n;
+	}
+	return n;
+}
+
+// PCR::find_target_match (pcr_assay.cpp:544): bits_out[i] = 0/1 per target.
+int ref_session_target_match(RefSession *s, const uint64_t pair[4], unsigned char *bits_out)
+{
+	try{
+		PCR p;
+		p.oligo( FORWARD, word_from(pair) );
+		p.oligo( REVERSE, word_from(pair + 2) );
+		BitSet m;
+		p.find_target_match(m, s->target_keys, s->target_db, s->target_seq, s->opt);
+		for(size_t i = 0;i < s->target_seq.size();++i){
+			bits_out[i] = ( (i < m.size()) && m[i] ) ? 1 : 0;
+		}
+		return 0;
+	}
+	catch(const char *e){ s->last_error = e; return -1; }
+	catch(...){ s->last_error = "unknown"; return -2; }
+}
+
+// The coverage evaluation of optimize() (optimize.cpp:61-74): collect with the search
+// threshold, update identities, sum weights.
+float ref_session_target_coverage(RefSession *s, const uint64_t pair[4])
+{
+	try{
+		PCR p;
+		p.oligo( FORWARD, word_from(pair) );
+		p.oligo( REVERSE, word_from(pair + 2) );
+		p.collect_target_candidates(s->target_keys, s->target_db, s->target_seq, s->opt);
+		p.update_target_candidates(s->target_keys, s->opt.use_taq_mama);
+		return p.compute_target_coverage(s->opt.target_threshold);
+	}
+	catch(const char *e){ s->last_error = e; return -1.0f; }
+	catch(...){ s->last_error = "unknown"; return -2.0f; }
+}
+
+// ---------------------------------------------------------------- Smith-Waterman (seq_overlap)
+// One 8-lane call exactly as background_match.cpp drives it: queries/targets are arrays of
+// SO_LEN 64-bit-pair Words (slot i of each).  Outputs per lane: score, query range, target
+// range, last-two-aligned target bases.
+int ref_sw_align_words(const uint64_t *query_words, const uint64_t *target_words,
+	int16_t *score, int32_t *qrange, int32_t *trange, uint8_t *last_two)
+{
+	try{
+		SO::SeqOverlap align(SO::SeqOverlap::SmithWaterman, true /*is_na*/);
+		for(unsigned i = 0;i < SO_LEN;++i){
+			align.pack_query_slots( (unsigned char)(1u << i), word_from(query_words + 2*i) );
+			align.pack_target_slots( (unsigned char)(1u << i), word_from(target_words + 2*i) );
+		}
+		align.align();
+		for(unsigned i = 0;i < SO_LEN;++i){
+			score[i] = align.score(i);
+			const pair<int,int> q = align.alignment_range_query(i);
+			const pair<int,int> t = align.alignment_range_target(i);
+			qrange[2*i] = q.first; qrange[2*i + 1] = q.second;
+			trange[2*i] = t.first; trange[2*i + 1] = t.second;
+			const pair<unsigned char, unsigned char> l2 = align.target_last_two_aligned(i);
+			last_two[2*i] = l2.first; last_two[2*i + 1] = l2.second;
+		}
+		return 0;
+	}
+	catch(const char *e){ return -1; }
+	catch(...){ return -2; }
+}
+
+// ---------------------------------------------------------------- NucCruc thermodynamics
+// out[0..3] = tm, dH, dS, dG(37C) of the perfect-match duplex; out[4] hairpin Tm;
+// out[5] homodimer Tm.
+int ref_thermo(const char *seq, float salt, float strand, float *out)
+{
+	try{
+		NucCruc melt;
+		melt.salt(salt);
+		melt.strand(strand);
+		const string s(seq);
+		out[0] = melt.tm_pm_duplex(s);
+		out[1] = melt.delta_H();
+		out[2] = melt.delta_S();
+		out[3] = melt.delta_G();
+		melt.set_query(s);
+		out[4] = melt.approximate_tm_hairpin();
+		out[5] = melt.approximate_tm_homodimer();
+		return 0;
+	}
+	catch(const char *e){ return -1; }
+	catch(...){ return -2; }
+}
+
+float ref_heterodimer(const char *a, const char *b, float salt, float strand_a, float strand_b)
+{
+	try{
+		NucCruc melt;
+		melt.salt(salt);
+		melt.strand(strand_a, strand_b);
+		melt.set_query( string(a) );
+		melt.set_target( string(b) );
+		return melt.approximate_tm_heterodimer();
+	}
+	catch(...){ return -1.0f; }
+}
+
+} // extern "C"

@@ -1,0 +1,291 @@
+"""Host-side mirror of the reference call sites, over the C-ABI in include/pcramp_hip.h.
+
+``Screener`` owns one GPU.  Its methods are named after what they replace in the reference:
+
+=====================  =======================================================================
+Screener method        reference call site
+=====================  =======================================================================
+load_sequences         deque<Sequence> after parse_fasta (main.cpp:257-344)
+set_active             Sequence::active(bool) (main.cpp:1105-1120)
+split                  Sequence::split_sequence (sequence.h:228; main.cpp:1008-1017)
+select_words           Sequence::pack + select_words per active sequence (main.cpp:579-615, 644-691)
+entries                the word DB `target_db` / `background_db`
+amplify                PCR::find_target_match + PCR::compute_coverage (pcr_assay.cpp:544, 271)
+find_target_match      PCR::find_target_match with Options' thresholds (main.cpp:898)
+compute_coverage       optimize()'s collect/update/compute_coverage (optimize.cpp:61-74)
+=====================  =======================================================================
+
+Errors surface as ``PcrError`` (the reference throws ``const char*``, main.cpp:1269).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import words as W
+
+TARGET, BACKGROUND = 0, 1
+
+
+class PcrError(RuntimeError):
+    pass
+
+
+class _Params(C.Structure):
+    _fields_ = [("pack_max_degen", C.c_uint32), ("pack_min_gc", C.c_float), ("pack_max_gc", C.c_float)]
+
+
+class _Entry(C.Structure):
+    _fields_ = [("w", C.c_uint64 * 2), ("loc", C.c_int32), ("index", C.c_uint32), ("strand", C.c_uint32),
+                ("pad", C.c_uint32)]
+
+
+class AmplifyArgs(C.Structure):
+    _fields_ = [("collect_threshold", C.c_float), ("ident_threshold", C.c_float), ("amp_min", C.c_int32),
+                ("amp_max", C.c_int32), ("use_taq_mama", C.c_int32)]
+
+
+def library_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libpcramp_hip.so")
+
+
+_LIB = None
+
+# every symbol include/pcramp_hip.h declares
+ABI_SYMBOLS = [
+    "pcr_last_error", "pcr_create", "pcr_destroy", "pcr_load_sequences", "pcr_set_active", "pcr_split",
+    "pcr_select_words", "pcr_get_entries", "pcr_amplify", "pcr_amplify_device", "pcr_coverage_from_bits",
+    "pcr_weighted_coverage", "pcr_num_sequences", "pcr_bitset_words", "pcr_profile_enable", "pcr_profile_read",
+    "pcr_synchronize", "pcr_host_irregular_words", "pcr_host_window_valid", "pcr_host_candidates",
+]
+
+
+def load_library():
+    """dlopen the in-tree C-ABI library.  Fails loudly if it was not built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise PcrError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(or make -C pcramp_amd/csrc); there is no CPU fallback" % path)
+    L = C.CDLL(path)
+    L.pcr_last_error.restype = C.c_char_p
+    L.pcr_create.restype = C.c_void_p
+    L.pcr_create.argtypes = [C.c_int, C.c_void_p, C.POINTER(_Params)]
+    L.pcr_destroy.argtypes = [C.c_void_p]
+    L.pcr_load_sequences.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+    L.pcr_set_active.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.pcr_split.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint64]
+    L.pcr_select_words.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_float,
+                                   C.c_uint32, C.POINTER(C.c_uint64)]
+    L.pcr_get_entries.restype = C.c_int64
+    L.pcr_get_entries.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]
+    L.pcr_amplify.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.POINTER(AmplifyArgs), C.c_void_p,
+                              C.c_void_p, C.c_void_p, C.c_void_p]
+    L.pcr_amplify_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.POINTER(AmplifyArgs),
+                                     C.c_void_p, C.c_void_p]
+    L.pcr_coverage_from_bits.restype = C.c_float
+    L.pcr_coverage_from_bits.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+    L.pcr_weighted_coverage.restype = C.c_float
+    L.pcr_weighted_coverage.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    L.pcr_num_sequences.restype = C.c_uint32
+    L.pcr_num_sequences.argtypes = [C.c_void_p, C.c_int]
+    L.pcr_bitset_words.restype = C.c_uint64
+    L.pcr_bitset_words.argtypes = [C.c_void_p, C.c_int]
+    L.pcr_profile_enable.argtypes = [C.c_void_p, C.c_int]
+    L.pcr_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
+    L.pcr_synchronize.argtypes = [C.c_void_p]
+    L.pcr_host_irregular_words.restype = C.c_int64
+    L.pcr_host_irregular_words.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(_Params), C.c_uint32, C.c_void_p, C.c_uint64]
+    L.pcr_host_window_valid.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(_Params), C.c_void_p]
+    L.pcr_host_candidates.restype = C.c_int64
+    L.pcr_host_candidates.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_uint64]
+    _LIB = L
+    return L
+
+
+def _err(L):
+    return (L.pcr_last_error() or b"").decode()
+
+
+# ---------------------------------------------------------------------------- host-only helpers
+def host_irregular_words(packed, length, min_oligo_length=18, pack_max_degen=256, pack_min_gc=0.0, pack_max_gc=1.0):
+    L = load_library()
+    p = _Params(pack_max_degen, pack_min_gc, pack_max_gc)
+    buf = np.ascontiguousarray(packed, dtype=np.uint8)
+    n = L.pcr_host_irregular_words(buf.ctypes.data, length, C.byref(p), min_oligo_length, None, 0)
+    if n < 0:
+        raise PcrError(_err(L))
+    out = (_Entry * max(int(n), 1))()
+    L.pcr_host_irregular_words(buf.ctypes.data, length, C.byref(p), min_oligo_length, out, n)
+    return [(e.w[0], e.w[1], e.loc, e.strand) for e in out[:n]]
+
+
+def host_window_valid(packed, length, pack_max_degen=256, pack_min_gc=0.0, pack_max_gc=1.0):
+    L = load_library()
+    p = _Params(pack_max_degen, pack_min_gc, pack_max_gc)
+    buf = np.ascontiguousarray(packed, dtype=np.uint8)
+    out = np.zeros(max(length, 1), dtype=np.uint8)
+    if L.pcr_host_window_valid(buf.ctypes.data, length, C.byref(p), out.ctypes.data) != 0:
+        raise PcrError(_err(L))
+    return out[:length]
+
+
+def host_candidates(pairs, optimize_5=False, optimize_3=False, threshold=0.9):
+    L = load_library()
+    a = W.pairs_array(pairs)
+    n = L.pcr_host_candidates(a.ctypes.data, len(pairs), int(optimize_5), int(optimize_3), threshold, None, None, 0)
+    words = np.zeros((max(int(n), 1), 2), dtype=np.uint64)
+    floors = np.zeros(max(int(n), 1), dtype=np.uint32)
+    L.pcr_host_candidates(a.ctypes.data, len(pairs), int(optimize_5), int(optimize_3), threshold,
+                          words.ctypes.data, floors.ctypes.data, n)
+    return [(int(words[i, 0]), int(words[i, 1])) for i in range(n)], floors[:n].copy()
+
+
+def coverage_from_bits(bits_fr, bits_rf, weights):
+    """PCR::compute_coverage's weight sum from (gathered) orientation bitsets."""
+    L = load_library()
+    a = np.ascontiguousarray(bits_fr, dtype=np.uint64)
+    b = np.ascontiguousarray(bits_rf, dtype=np.uint64)
+    w = np.ascontiguousarray(weights, dtype=np.float32)
+    return L.pcr_coverage_from_bits(a.ctypes.data, b.ctypes.data, w.ctypes.data, w.size)
+
+
+def weighted_coverage(bits, weights):
+    L = load_library()
+    a = np.ascontiguousarray(bits, dtype=np.uint64)
+    w = np.ascontiguousarray(weights, dtype=np.float32)
+    return L.pcr_weighted_coverage(a.ctypes.data, w.ctypes.data, w.size)
+
+
+def bits_to_bool(words, n):
+    """u64 bitset words (bit i%64 of word i//64) -> bool array of n."""
+    w = np.ascontiguousarray(words, dtype=np.uint64)
+    b = np.unpackbits(w.view(np.uint8), bitorder="little")
+    return b[:n].astype(bool)
+
+
+# ---------------------------------------------------------------------------- the device handle
+class Screener:
+    """One GPU's share of the sequence sets plus the kernels that evaluate primer pairs on it."""
+
+    def __init__(self, device=0, stream=None, pack_max_degen=256, pack_min_gc=0.0, pack_max_gc=1.0):
+        self.L = load_library()
+        p = _Params(pack_max_degen, pack_min_gc, pack_max_gc)
+        self.h = self.L.pcr_create(device, C.c_void_p(stream) if stream else None, C.byref(p))
+        if not self.h:
+            raise PcrError(_err(self.L))
+        self.weights = {TARGET: np.zeros(0, np.float32), BACKGROUND: np.zeros(0, np.float32)}
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.pcr_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise PcrError(_err(self.L))
+
+    def load_sequences(self, packed, byte_offsets, lengths, weights=None, which=TARGET):
+        packed = np.ascontiguousarray(packed, dtype=np.uint8)
+        bo = np.ascontiguousarray(byte_offsets, dtype=np.uint64)
+        ln = np.ascontiguousarray(lengths, dtype=np.uint64)
+        n = ln.size
+        w = np.ones(n, np.float32) if weights is None else np.ascontiguousarray(weights, dtype=np.float32)
+        self.weights[which] = w
+        self._check(self.L.pcr_load_sequences(self.h, which, packed.ctypes.data, bo.ctypes.data, ln.ctypes.data,
+                                              w.ctypes.data, n))
+
+    def load_texts(self, seqs, weights=None, which=TARGET):
+        """Convenience for tests: IUPAC strings ('-' = EOS)."""
+        packs = [W.pack_codes(W.codes_from_text(s)) for s in seqs]
+        lengths = [len(s) for s in seqs]
+        off = np.zeros(len(seqs), dtype=np.uint64)
+        tot = 0
+        for i, p in enumerate(packs):
+            off[i] = tot
+            tot += p.size
+        packed = np.concatenate(packs) if packs else np.zeros(0, np.uint8)
+        self.load_sequences(packed, off, lengths, weights, which)
+
+    def num_sequences(self, which=TARGET):
+        return self.L.pcr_num_sequences(self.h, which)
+
+    def bitset_words(self, which=TARGET):
+        return self.L.pcr_bitset_words(self.h, which)
+
+    def set_active(self, active, which=TARGET):
+        a = np.ascontiguousarray(np.asarray(active).astype(np.uint8))
+        self._check(self.L.pcr_set_active(self.h, which, a.ctypes.data))
+
+    def split(self, seq, pos, which=TARGET):
+        self._check(self.L.pcr_split(self.h, which, seq, pos))
+
+    def select_words(self, pairs, threshold, min_oligo_length=18, optimize_5=False, optimize_3=False, which=TARGET):
+        a = pairs if isinstance(pairs, np.ndarray) else W.pairs_array(pairs)
+        n = C.c_uint64(0)
+        self._check(self.L.pcr_select_words(self.h, which, a.ctypes.data, a.shape[0], int(optimize_5), int(optimize_3),
+                                            threshold, min_oligo_length, C.byref(n)))
+        return n.value
+
+    def entries(self, which=TARGET):
+        n = self.L.pcr_get_entries(self.h, which, None, 0)
+        if n < 0:
+            raise PcrError(_err(self.L))
+        buf = (_Entry * max(int(n), 1))()
+        self.L.pcr_get_entries(self.h, which, buf, n)
+        return sorted((e.w[0], e.w[1], e.loc, e.index, e.strand) for e in buf[:n])
+
+    def amplify(self, pairs, collect_threshold, ident_threshold, amp_min=80, amp_max=200, use_taq_mama=False,
+                which=TARGET):
+        """-> (bits[n_pairs, n] bool, bits_fr, bits_rf, coverage[n_pairs] float32)."""
+        a = pairs if isinstance(pairs, np.ndarray) else W.pairs_array(pairs)
+        P = a.shape[0]
+        nw = int(self.bitset_words(which))
+        n = self.num_sequences(which)
+        bits = np.zeros((P, nw), np.uint64)
+        fr = np.zeros((P, nw), np.uint64)
+        rf = np.zeros((P, nw), np.uint64)
+        cov = np.zeros(P, np.float32)
+        args = AmplifyArgs(collect_threshold, ident_threshold, amp_min, amp_max, int(use_taq_mama))
+        self._check(self.L.pcr_amplify(self.h, which, a.ctypes.data, P, C.byref(args), bits.ctypes.data,
+                                       fr.ctypes.data, rf.ctypes.data, cov.ctypes.data))
+        tb = lambda x: np.stack([bits_to_bool(x[i], n) for i in range(P)]) if P else np.zeros((0, n), bool)
+        return tb(bits), tb(fr), tb(rf), cov
+
+    def amplify_device(self, pairs, d_fr_ptr, d_rf_ptr, collect_threshold, ident_threshold, amp_min=80, amp_max=200,
+                       use_taq_mama=False, which=TARGET):
+        a = pairs if isinstance(pairs, np.ndarray) else W.pairs_array(pairs)
+        args = AmplifyArgs(collect_threshold, ident_threshold, amp_min, amp_max, int(use_taq_mama))
+        self._check(self.L.pcr_amplify_device(self.h, which, a.ctypes.data, a.shape[0], C.byref(args),
+                                              C.c_void_p(d_fr_ptr), C.c_void_p(d_rf_ptr)))
+
+    # -- the two reference evaluations, with Options-style arguments
+    def find_target_match(self, pairs, target_threshold=1.0, amp_min=80, amp_max=200, use_taq_mama=False, which=TARGET):
+        """PCR::find_target_match (pcr_assay.cpp:544): collect at target_threshold, test at target_threshold."""
+        return self.amplify(pairs, target_threshold, target_threshold, amp_min, amp_max, use_taq_mama, which)[0]
+
+    def compute_coverage(self, pairs, target_threshold=1.0, search_multiplier=0.9, amp_min=80, amp_max=200,
+                         use_taq_mama=False, which=TARGET):
+        """optimize.cpp:61-74: collect at threshold*multiplier (float product), test at threshold."""
+        ct = float(np.float32(target_threshold) * np.float32(search_multiplier))
+        return self.amplify(pairs, ct, target_threshold, amp_min, amp_max, use_taq_mama, which)[3]
+
+    def profile(self, on=True):
+        self._check(self.L.pcr_profile_enable(self.h, int(on)))
+
+    def profile_read(self, reset=True):
+        ms = C.c_double(0.0)
+        n = C.c_uint64(0)
+        self._check(self.L.pcr_profile_read(self.h, C.byref(ms), C.byref(n), int(reset)))
+        return ms.value, n.value
+
+    def synchronize(self):
+        self._check(self.L.pcr_synchronize(self.h))

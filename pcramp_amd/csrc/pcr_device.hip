@@ -1,0 +1,1057 @@
+// MI355X (gfx950) implementation of the C-ABI in include/pcramp_hip.h.
+//
+// HBM layout (per sequence set)
+//   planes[]  : one uint4 {A,C,G,T} per 32-base block; bit j of .x = base 32*b+j may be 'A', ...
+//               (the reference's 4-bit IUPAC nibble, bit-transposed: same 4 bits/base as
+//               Sequence::seq_buffer, sequence.h:86).  EOS / past-the-end = no bit in any plane.
+//               Each sequence owns ceil(L/32)+2 blocks (two zero halo blocks).
+//   valid[]   : one u32 per block; bit j = the 32-base window starting at 32*b+j is a REGULAR
+//               window that Sequence::pack emits (sequence.cpp:127-153 filters applied).
+//   irr[]     : explicit irregular words (pcr_host.hpp).
+// Kernels
+//   k_transpose, k_valid  : load-time index build (replaces Sequence::operator= + the filter half of pack)
+//   k_scan, k_scan_irr    : oligo x window match counts + per-(sequence,candidate) running max
+//                           (select_words.cpp:88-117 over the implicit word index)
+//   k_filter, k_entries   : arg-max-with-ties selection -> the device word DB (select_words.cpp:126-138)
+//   k_match, k_pair       : match_words / find_oligo_match / find_amplicon_match / update_identity /
+//                           sqrtf(f*r) test (optimize.cpp:209-301, pcr_assay.cpp:12-69,338-441,544-578)
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <stdint.h>
+#include <string.h>
+#include <math.h>
+#include <string>
+#include <vector>
+#include <algorithm>
+
+#include "../../include/pcramp_hip.h"
+#include "pcr_host.hpp"
+
+using pcrhost::Planes;
+
+namespace {
+
+thread_local std::string g_err;
+
+#define HIP_TRY(expr) do{ hipError_t e_ = (expr); if(e_ != hipSuccess){ \
+	g_err = std::string(#expr) + ": " + hipGetErrorString(e_); return PCR_ERR_DEVICE; } }while(0)
+
+constexpr int TILE_POS = 1024;       // window starts per workgroup
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_NPOS = TILE_POS/SCAN_THREADS;
+
+// dedupe / sort key of a DB entry: [seq:24][loc+64:32][strand-1:1][kind:1][ord:6]
+constexpr int KEY_SEQ_SHIFT = 40;
+constexpr int KEY_LOC_SHIFT = 8;
+constexpr int LOC_BIAS = 64;
+
+struct Hit { uint64_t key; uint32_t cand; uint32_t cnt; };
+
+struct IrrDev { Planes w; int32_t loc; uint32_t seq; uint32_t meta; /* strand | cws<<8 | ord<<16 */ uint32_t local_id; };
+
+struct DevEntry { Planes w; int32_t loc; uint32_t seq; uint32_t strand; uint32_t pad; };
+
+struct OligoDev {        // one assay oligo for the amplicon screen
+	Planes m;
+	uint32_t floor2;     // unsigned(size * thr^2), optimize.cpp:293
+	float norm;          // float(1.0/len), optimize.cpp:221
+	int32_t start, stop; // Word::start()/stop()
+	uint32_t p1, p2;     // last two primer bases (optimize.cpp:236)
+};
+
+__constant__ float c_taq_mama[256];
+
+// word.cpp:252-272 -- Table 2 of Li et al., Genomics 83 (2004) 311-320 (rows: template pair,
+// columns: primer pair, order {CC,GC,AC,TC,CG,GG,AG,TG,CA,GA,AA,TA,CT,GT,AT,TT}).
+const float h_taq_mama[256] = {
+	1.000f, 0.968f, 0.947f, 1.034f, 0.547f, 0.253f, 0.230f, 0.359f, 0.606f, 0.282f, 0.372f, 0.347f, 0.957f, 0.382f, 0.399f, 0.687f,
+	0.989f, 1.000f, 1.023f, 1.000f, 0.420f, 0.662f, 0.445f, 0.367f, 0.870f, 0.512f, 0.492f, 0.508f, 0.372f, 1.000f, 0.492f, 0.714f,
+	1.011f, 1.000f, 1.000f, 1.000f, 0.459f, 0.277f, 0.570f, 0.343f, 0.927f, 0.362f, 0.590f, 0.542f, 0.439f, 0.488f, 0.978f, 0.662f,
+	1.000f, 0.907f, 1.000f, 1.000f, 0.382f, 0.234f, 0.228f, 0.542f, 0.763f, 0.309f, 0.410f, 0.473f, 0.426f, 0.347f, 0.423f, 0.947f,
+	0.590f, 0.334f, 0.445f, 0.323f, 1.000f, 0.978f, 0.927f, 0.989f, 0.907f, 0.645f, 0.525f, 0.455f, 0.927f, 0.408f, 0.408f, 0.707f,
+	0.327f, 0.595f, 0.319f, 0.396f, 0.947f, 1.000f, 0.978f, 0.989f, 0.405f, 0.861f, 0.681f, 0.512f, 0.410f, 0.968f, 0.452f, 0.714f,
+	0.410f, 0.420f, 0.590f, 0.311f, 1.023f, 1.000f, 1.000f, 1.000f, 0.488f, 0.898f, 0.907f, 0.566f, 0.442f, 0.449f, 0.989f, 0.707f,
+	0.423f, 0.343f, 0.305f, 0.585f, 1.034f, 0.879f, 0.927f, 1.000f, 0.473f, 0.720f, 0.547f, 0.957f, 0.459f, 0.374f, 0.459f, 1.023f,
+	1.023f, 0.429f, 0.473f, 0.477f, 1.023f, 0.466f, 0.420f, 0.477f, 1.000f, 0.978f, 0.907f, 0.978f, 0.907f, 0.380f, 0.525f, 0.669f,
+	0.442f, 1.046f, 0.455f, 0.470f, 0.432f, 1.058f, 0.481f, 0.485f, 0.917f, 1.000f, 1.023f, 1.023f, 0.336f, 0.968f, 0.534f, 0.639f,
+	0.617f, 0.452f, 1.011f, 0.439f, 0.492f, 0.504f, 0.978f, 0.462f, 0.989f, 0.947f, 1.000f, 0.978f, 0.405f, 0.405f, 0.888f, 0.606f,
+	0.601f, 0.377f, 0.377f, 1.046f, 0.500f, 0.399f, 0.408f, 1.034f, 0.978f, 0.720f, 0.870f, 1.000f, 0.402f, 0.313f, 0.651f, 0.927f,
+	0.978f, 0.462f, 0.466f, 0.488f, 0.420f, 0.239f, 0.225f, 0.336f, 0.504f, 0.269f, 0.319f, 0.656f, 1.000f, 0.835f, 0.907f, 1.034f,
+	0.429f, 1.011f, 0.473f, 0.477f, 0.340f, 0.413f, 0.357f, 0.354f, 0.352f, 0.538f, 0.413f, 0.794f, 0.927f, 1.000f, 1.058f, 1.000f,
+	0.595f, 0.492f, 0.968f, 0.485f, 0.367f, 0.282f, 0.388f, 0.439f, 0.413f, 0.309f, 0.566f, 0.917f, 0.957f, 0.957f, 1.000f, 0.989f,
+	0.590f, 0.380f, 0.410f, 0.968f, 0.364f, 0.223f, 0.230f, 0.416f, 0.321f, 0.239f, 0.301f, 0.645f, 0.978f, 0.714f, 0.947f, 1.000f
+};
+
+// ============================================================================== device helpers
+__device__ __forceinline__ uint32_t funnel(uint32_t lo, uint32_t hi, uint32_t sh)
+{
+	return __builtin_amdgcn_alignbit(hi, lo, sh);   // ({hi,lo} >> (sh & 31)) & 0xffffffff
+}
+
+__device__ __forceinline__ uint32_t match_count(uint32_t wa, uint32_t wc, uint32_t wg, uint32_t wt, const uint4 m)
+{
+	// # slots whose base sets intersect == Word::operator& (word.cpp:151-154) in plane form
+	return __popc((wa & m.x) | (wc & m.y) | (wg & m.z) | (wt & m.w));
+}
+
+// ============================================================================== load-time kernels
+// One thread per 32-base block: nibbles (high first, sequence.h:223-228) -> four bit planes.
+__global__ void k_transpose(const uint8_t *__restrict__ packed, const uint64_t *__restrict__ byte_off,
+	const uint64_t *__restrict__ len, const uint64_t *__restrict__ blk_off, const uint32_t *__restrict__ blk_seq,
+	uint4 *__restrict__ planes, uint64_t total_blocks)
+{
+	const uint64_t gb = (uint64_t)blockIdx.x*blockDim.x + threadIdx.x;
+	if(gb >= total_blocks) return;
+	const uint32_t s = blk_seq[gb];
+	const uint64_t b = gb - blk_off[s];
+	const uint64_t L = len[s];
+	const uint8_t *src = packed + byte_off[s];
+	uint32_t a = 0, c = 0, g = 0, t = 0;
+	for(int j = 0;j < 32;++j){
+		const uint64_t pos = b*32 + j;
+		if(pos >= L) break;
+		const uint8_t v = src[pos >> 1];
+		const uint32_t nib = (pos & 1) ? (v & 0xF) : (v >> 4);
+		a |= (nib & 1u) << j;
+		c |= ((nib >> 1) & 1u) << j;
+		g |= ((nib >> 2) & 1u) << j;
+		t |= ((nib >> 3) & 1u) << j;
+	}
+	planes[gb] = make_uint4(a, c, g, t);
+}
+
+// One thread per block: validity of the 32 windows that START in it.  A window is regular iff
+// all 32 slots are non-EOS; then pack's filters (GC first, then degeneracy; sequence.cpp:127-153).
+__global__ void k_valid(const uint4 *__restrict__ planes, const uint64_t *__restrict__ blk_off,
+	const uint32_t *__restrict__ blk_seq, const uint64_t *__restrict__ nblk_real, uint32_t *__restrict__ valid,
+	uint64_t total_blocks, uint32_t max_degen, uint64_t gc_ok, uint64_t first_block, uint64_t n_blocks)
+{
+	const uint64_t i = (uint64_t)blockIdx.x*blockDim.x + threadIdx.x;
+	if(i >= n_blocks) return;
+	const uint64_t gb = first_block + i;
+	if(gb >= total_blocks) return;
+	const uint32_t s = blk_seq[gb];
+	const uint64_t b = gb - blk_off[s];
+	// halo blocks start no window
+	if(b >= nblk_real[s]){ valid[gb] = 0; return; }
+	const uint4 lo = planes[gb];
+	const uint4 hi = planes[gb + 1];   // exists: every sequence has two halo blocks
+	// per-position base multiplicity planes
+	uint32_t nzl, d2l, d3l, d4l, cgl, nzh, d2h, d3h, d4h, cgh;
+	{
+		const uint32_t x = lo.x ^ lo.y, y = lo.x & lo.y, u = lo.z ^ lo.w, v = lo.z & lo.w;
+		const uint32_t ones = x ^ u, c1 = x & u;
+		const uint32_t twos = y ^ v ^ c1;
+		const uint32_t fours = (y & v) | (c1 & (y ^ v));
+		nzl = lo.x | lo.y | lo.z | lo.w;
+		d2l = ~ones & twos & ~fours; d3l = ones & twos; d4l = fours;
+		cgl = lo.y | lo.z;
+	}
+	{
+		const uint32_t x = hi.x ^ hi.y, y = hi.x & hi.y, u = hi.z ^ hi.w, v = hi.z & hi.w;
+		const uint32_t ones = x ^ u, c1 = x & u;
+		const uint32_t twos = y ^ v ^ c1;
+		const uint32_t fours = (y & v) | (c1 & (y ^ v));
+		nzh = hi.x | hi.y | hi.z | hi.w;
+		d2h = ~ones & twos & ~fours; d3h = ones & twos; d4h = fours;
+		cgh = hi.y | hi.z;
+	}
+	uint32_t out = 0;
+	for(uint32_t j = 0;j < 32;++j){
+		if(funnel(nzl, nzh, j) != 0xFFFFFFFFu) continue;
+		const uint32_t ngc = __popc(funnel(cgl, cgh, j));
+		if(!((gc_ok >> ngc) & 1ull)) continue;
+		const uint32_t n2 = __popc(funnel(d2l, d2h, j));
+		const uint32_t n3 = __popc(funnel(d3l, d3h, j));
+		const uint32_t n4 = __popc(funnel(d4l, d4h, j));
+		// Word::degeneracy() > thr, exact integer form (pcr_host.hpp: degeneracy_exceeds)
+		const uint32_t e = n2 + 2*n4;
+		bool exceeds;
+		if(e >= 33){ exceeds = true; }
+		else{
+			uint64_t p3 = 1;
+			for(uint32_t k = 0;k < n3;++k) p3 *= 3;
+			exceeds = p3 > ((uint64_t)max_degen >> e);
+		}
+		if(!exceeds) out |= (1u << j);
+	}
+	valid[gb] = out;
+}
+
+// ============================================================================== select_words
+__device__ __noinline__ void record_hit(uint32_t *__restrict__ best, Hit *__restrict__ hits,
+	uint32_t *__restrict__ counters, uint32_t hit_cap, uint32_t ncand,
+	uint32_t seq, uint32_t cand, uint64_t key, uint32_t cnt)
+{
+	const uint32_t old = atomicMax(&best[(size_t)seq*ncand + cand], cnt);
+	if(cnt >= old){
+		const uint32_t idx = atomicAdd(&counters[0], 1u);
+		if(idx < hit_cap){
+			Hit h; h.key = key; h.cand = cand; h.cnt = cnt;
+			hits[idx] = h;
+		}
+	}
+}
+
+__device__ __forceinline__ uint64_t make_key(uint32_t seq, int32_t loc, uint32_t strand /*1|2*/, uint32_t kind, uint32_t ord)
+{
+	return ((uint64_t)seq << KEY_SEQ_SHIFT) | ((uint64_t)(uint32_t)(loc + LOC_BIAS) << KEY_LOC_SHIFT) |
+		((uint64_t)(strand - 1) << 7) | ((uint64_t)kind << 6) | ord;
+}
+
+// v1 match scan: one lane = one window start; the window's four 32-bit plane slices live in
+// registers; candidates are wave-uniform (scalar loads), 4 and/or + popcount + compare each.
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan(
+	const uint4 *__restrict__ planes, const uint32_t *__restrict__ valid,
+	const uint64_t *__restrict__ blk_off, const uint64_t *__restrict__ len, const uint8_t *__restrict__ active,
+	const uint32_t *__restrict__ tile_seq, const uint32_t *__restrict__ tile_pos0,
+	const uint4 *__restrict__ cand_fwd, const uint4 *__restrict__ cand_rc, const uint32_t *__restrict__ cand_floor,
+	uint32_t ncand, uint32_t *__restrict__ best, Hit *__restrict__ hits, uint32_t *__restrict__ counters, uint32_t hit_cap)
+{
+	const uint32_t tile = blockIdx.x;
+	const uint32_t seq = tile_seq[tile];
+	if(!active[seq]) return;
+	const uint64_t L = len[seq];
+	const uint64_t base = blk_off[seq];
+	const uint32_t p0 = tile_pos0[tile];
+
+	uint32_t wa[SCAN_NPOS], wc[SCAN_NPOS], wg[SCAN_NPOS], wt[SCAN_NPOS], ok[SCAN_NPOS];
+#pragma unroll
+	for(int i = 0;i < SCAN_NPOS;++i){
+		const uint32_t p = p0 + threadIdx.x + SCAN_THREADS*i;
+		wa[i] = wc[i] = wg[i] = wt[i] = 0; ok[i] = 0;
+		if((uint64_t)p + 32 <= L){
+			const uint32_t b = p >> 5, sh = p & 31;
+			const uint4 lo = planes[base + b];
+			const uint4 hi = planes[base + b + 1];
+			wa[i] = funnel(lo.x, hi.x, sh); wc[i] = funnel(lo.y, hi.y, sh);
+			wg[i] = funnel(lo.z, hi.z, sh); wt[i] = funnel(lo.w, hi.w, sh);
+			ok[i] = (valid[base + b] >> sh) & 1u;
+		}
+	}
+
+	for(uint32_t c = 0;c < ncand;++c){
+		const uint4 mf = cand_fwd[c];
+		const uint4 mr = cand_rc[c];
+		const uint32_t fl = cand_floor[c];
+#pragma unroll
+		for(int i = 0;i < SCAN_NPOS;++i){
+			const uint32_t cf = match_count(wa[i], wc[i], wg[i], wt[i], mf);
+			const uint32_t cr = match_count(wa[i], wc[i], wg[i], wt[i], mr);
+			if((cf >= fl || cr >= fl) && ok[i]){
+				const int32_t p = (int32_t)(p0 + threadIdx.x + SCAN_THREADS*i);
+				if(cf >= fl) record_hit(best, hits, counters, hit_cap, ncand, seq, c, make_key(seq, p, 1, 0, 0), cf);       // sequence.cpp:184
+				if(cr >= fl) record_hit(best, hits, counters, hit_cap, ncand, seq, c, make_key(seq, p + 31, 2, 0, 0), cr);  // sequence.cpp:190
+			}
+		}
+	}
+}
+
+// Irregular words: one lane per word, candidates uniform.
+__global__ void k_scan_irr(const IrrDev *__restrict__ irr, uint32_t n_irr, const uint8_t *__restrict__ active,
+	uint32_t min_len, const uint4 *__restrict__ cand_fwd, const uint32_t *__restrict__ cand_floor, uint32_t ncand,
+	uint32_t *__restrict__ best, Hit *__restrict__ hits, uint32_t *__restrict__ counters, uint32_t hit_cap)
+{
+	const uint32_t i = blockIdx.x*blockDim.x + threadIdx.x;
+	if(i >= n_irr) return;
+	const IrrDev e = irr[i];
+	if(!active[e.seq]) return;
+	const uint32_t cws = (e.meta >> 8) & 0xFF;
+	if(cws < min_len) return;                                                    // sequence.cpp:157,239
+	const uint32_t strand = e.meta & 0xFF, ord = (e.meta >> 16) & 0xFF;
+	const uint64_t key = make_key(e.seq, e.loc, strand, 1, ord);
+	for(uint32_t c = 0;c < ncand;++c){
+		const uint32_t cnt = match_count(e.w.a, e.w.c, e.w.g, e.w.t, cand_fwd[c]);
+		if(cnt >= cand_floor[c]) record_hit(best, hits, counters, hit_cap, ncand, e.seq, c, key, cnt);
+	}
+}
+
+// Keep the hits that attain the final per-(sequence,candidate) maximum (select_words.cpp:100-117).
+__global__ void k_filter(const Hit *__restrict__ hits, uint32_t n_hits, const uint32_t *__restrict__ best,
+	uint32_t ncand, uint64_t *__restrict__ keys, uint32_t *__restrict__ counters)
+{
+	const uint32_t i = blockIdx.x*blockDim.x + threadIdx.x;
+	if(i >= n_hits) return;
+	const Hit h = hits[i];
+	const uint32_t seq = (uint32_t)(h.key >> KEY_SEQ_SHIFT);
+	if(h.cnt == best[(size_t)seq*ncand + h.cand]){
+		const uint32_t k = atomicAdd(&counters[1], 1u);
+		keys[k] = h.key;   // capacity == hit capacity >= n_hits
+	}
+}
+
+// Sorted unique keys -> materialised DB entries + per-sequence segments.
+__global__ void k_entries(const uint64_t *__restrict__ keys, uint32_t n, const uint4 *__restrict__ planes,
+	const uint64_t *__restrict__ blk_off, const IrrDev *__restrict__ irr, const uint32_t *__restrict__ irr_off,
+	DevEntry *__restrict__ out, uint32_t *__restrict__ seg_lo, uint32_t *__restrict__ seg_hi)
+{
+	const uint32_t i = blockIdx.x*blockDim.x + threadIdx.x;
+	if(i >= n) return;
+	const uint64_t k = keys[i];
+	const uint32_t seq = (uint32_t)(k >> KEY_SEQ_SHIFT);
+	const int32_t loc = (int32_t)(uint32_t)((k >> KEY_LOC_SHIFT) & 0xFFFFFFFFull) - LOC_BIAS;
+	const uint32_t strand = (uint32_t)((k >> 7) & 1) + 1;
+	const uint32_t kind = (uint32_t)((k >> 6) & 1), ord = (uint32_t)(k & 63);
+	DevEntry e;
+	e.loc = loc; e.seq = seq; e.strand = strand; e.pad = 0;
+	if(kind == 0){
+		const uint32_t p = (strand == 1) ? (uint32_t)loc : (uint32_t)(loc - 31);
+		const uint32_t b = p >> 5, sh = p & 31;
+		const uint4 lo = planes[blk_off[seq] + b];
+		const uint4 hi = planes[blk_off[seq] + b + 1];
+		const uint32_t a = funnel(lo.x, hi.x, sh), c = funnel(lo.y, hi.y, sh);
+		const uint32_t g = funnel(lo.z, hi.z, sh), t = funnel(lo.w, hi.w, sh);
+		if(strand == 1){ e.w.a = a; e.w.c = c; e.w.g = g; e.w.t = t; }
+		else{ e.w.a = __brev(t); e.w.t = __brev(a); e.w.c = __brev(g); e.w.g = __brev(c); }   // Word::complement, word.h:140
+	}
+	else{
+		// find the irregular word with this (loc, strand, ord) in the sequence's list
+		e.w.a = e.w.c = e.w.g = e.w.t = 0;
+		for(uint32_t j = irr_off[seq];j < irr_off[seq + 1];++j){
+			const IrrDev r = irr[j];
+			if(r.loc == loc && (r.meta & 0xFF) == strand && ((r.meta >> 16) & 0xFF) == ord){ e.w = r.w; break; }
+		}
+	}
+	out[i] = e;
+	if(i == 0 || (uint32_t)(keys[i - 1] >> KEY_SEQ_SHIFT) != seq) seg_lo[seq] = i;
+	if(i == n - 1 || (uint32_t)(keys[i + 1] >> KEY_SEQ_SHIFT) != seq) seg_hi[seq] = i + 1;
+}
+
+// ============================================================================== amplicon screen
+// match_words (optimize.cpp:291-301) of every assay oligo against every DB entry:
+// mask[e][o/32] bit o%32 = entry matches oligo o at or above unsigned(size*thr^2).
+__global__ void k_match(const DevEntry *__restrict__ db, uint32_t n, const OligoDev *__restrict__ oligos,
+	uint32_t n_oligo, uint32_t mask_words, uint32_t *__restrict__ mask)
+{
+	const uint32_t i = blockIdx.x*blockDim.x + threadIdx.x;
+	if(i >= n) return;
+	const DevEntry e = db[i];
+	for(uint32_t w = 0;w < mask_words;++w){
+		uint32_t bits = 0;
+		const uint32_t o_end = min(n_oligo, (w + 1)*32);
+		for(uint32_t o = w*32;o < o_end;++o){
+			const Planes m = oligos[o].m;
+			const uint32_t cnt = __popc((e.w.a & m.a) | (e.w.c & m.c) | (e.w.g & m.g) | (e.w.t & m.t));
+			bits |= (uint32_t)(cnt >= oligos[o].floor2) << (o & 31);
+		}
+		mask[(size_t)i*mask_words + w] = bits;
+	}
+}
+
+__device__ __forceinline__ uint32_t nibble_at(const Planes &p, int k)
+{
+	return ((p.a >> k) & 1u) | (((p.c >> k) & 1u) << 1) | (((p.g >> k) & 1u) << 2) | (((p.t >> k) & 1u) << 3);
+}
+
+__device__ __forceinline__ bool nondegen(uint32_t v) { return v == 1 || v == 2 || v == 4 || v == 8; }   // base_table.h:125
+
+__device__ __forceinline__ int taq_idx(uint32_t v) { return (v == 2) ? 0 : (v == 4) ? 1 : (v == 1) ? 2 : 3; } // word.cpp:233
+
+// update_identity for one (oligo, key) (optimize.cpp:209-261)
+__device__ float identity(const OligoDev &o, const Planes &key, int use_taq)
+{
+	const uint32_t cnt = __popc((key.a & o.m.a) | (key.c & o.m.c) | (key.g & o.m.g) | (key.t & o.m.t));
+	float id = __fmul_rn((float)cnt, o.norm);
+	if(use_taq && nondegen(o.p1) && nondegen(o.p2)){
+		const uint32_t t1 = nibble_at(key, o.stop - 1), t2 = nibble_at(key, o.stop);
+		if(nondegen(t1) && nondegen(t2)){
+			const float corr = fminf(1.0f, c_taq_mama[16*(4*taq_idx(t2) + taq_idx(t1)) + (4*taq_idx(o.p2) + taq_idx(o.p1))]);
+			id = __fmul_rn(id, corr);
+		}
+	}
+	return id;
+}
+
+// Sequence::has_split (sequence.cpp:304-330) on the plane store: any EOS in [start, start+n)?
+__device__ bool has_split(const uint4 *__restrict__ planes, uint64_t base, int32_t start, int32_t n)
+{
+	int32_t pos = start;
+	const int32_t end = start + n;
+	while(pos < end){
+		const uint32_t b = (uint32_t)pos >> 5, sh = (uint32_t)pos & 31;
+		const uint4 v = planes[base + b];
+		uint32_t nz = (v.x | v.y | v.z | v.w) >> sh;
+		const int32_t span = min(32 - (int32_t)sh, end - pos);
+		const uint32_t want = (span == 32) ? 0xFFFFFFFFu : ((1u << span) - 1u);
+		if((nz & want) != want) return true;
+		pos += span;
+	}
+	return false;
+}
+
+// One lane per plus-strand DB entry i; it walks the later entries j of the same sequence
+// (sorted by WordMatch::loc, as assay.h:48-61) and, for every assay pair matched by both,
+// applies find_amplicon_match (pcr_assay.cpp:338-441) and the identity test.
+__global__ void k_pair(const DevEntry *__restrict__ db, uint32_t n, const uint32_t *__restrict__ seg_hi,
+	const uint32_t *__restrict__ mask, uint32_t mask_words, const OligoDev *__restrict__ oligos, uint32_t n_pairs,
+	const uint4 *__restrict__ planes, const uint64_t *__restrict__ blk_off, const uint64_t *__restrict__ len,
+	const uint8_t *__restrict__ active, int32_t amp_min, int32_t amp_max, float ident_thr, int use_taq,
+	uint64_t *__restrict__ bits_fr, uint64_t *__restrict__ bits_rf, uint64_t bit_words, uint32_t *__restrict__ status)
+{
+	const uint32_t i = blockIdx.x*blockDim.x + threadIdx.x;
+	if(i >= n) return;
+	const DevEntry ei = db[i];
+	if(ei.strand != 1) return;
+	if(!active[ei.seq]) return;                                                  // optimize.cpp:281
+	const uint32_t hi = seg_hi[ei.seq];
+	const int32_t L = (int32_t)len[ei.seq];
+	const uint64_t base = blk_off[ei.seq];
+	for(uint32_t j = i + 1;j < hi;++j){
+		const DevEntry ej = db[j];
+		if(ej.loc - ei.loc > amp_max + 128) break;   // beyond any admissible amplicon (slack: slots + end clamp)
+		if(ej.strand != 2) continue;
+		for(uint32_t w = 0;w < mask_words;++w){
+			// oligo o = 2*pair + {0:F, 1:R}; F bits are the even bits, R bits the odd bits
+			const uint32_t mi = mask[(size_t)i*mask_words + w], mj = mask[(size_t)j*mask_words + w];
+			// orientation FR: F matches plus entry i, R matches minus entry j
+			uint32_t fr = mi & (mj >> 1) & 0x55555555u;
+			// orientation RF: R matches plus entry i, F matches minus entry j
+			uint32_t rf = (mi >> 1) & mj & 0x55555555u;
+			uint32_t any = fr | rf;
+			while(any){
+				const uint32_t bit = __ffs(any) - 1;
+				any &= any - 1;
+				const uint32_t pair = (w*32 + bit) >> 1;
+				if(pair >= n_pairs) break;
+				const OligoDev F = oligos[2*pair], R = oligos[2*pair + 1];
+				for(int orient = 0;orient < 2;++orient){
+					if(!(((orient == 0) ? fr : rf) >> bit & 1u)) continue;
+					const OligoDev &P = (orient == 0) ? F : R;   // plus-role oligo
+					const OligoDev &M = (orient == 0) ? R : F;   // minus-role oligo
+					// pcr_assay.cpp:367-370 (WordMatch::template_loc3 / loc5, sequence.h:57-75)
+					if(ei.loc + P.stop >= ej.loc - M.stop) continue;
+					int32_t amp_start = ei.loc + P.start;
+					const int32_t amp_stop = min(ej.loc - M.start, L - 1);
+					int32_t amp_len = amp_stop - amp_start + 1;
+					if(amp_len < amp_min || amp_len > amp_max) continue;
+					if(amp_start < 0){ amp_len += amp_start; amp_start = 0; }
+					if(amp_len < 0 || amp_start + amp_len > L){ atomicOr(status, 1u); continue; }   // sequence.cpp:306 throw
+					if(has_split(planes, base, amp_start, amp_len)) continue;
+					const float f = identity(F, (orient == 0) ? ei.w : ej.w, use_taq);
+					const float r = identity(R, (orient == 0) ? ej.w : ei.w, use_taq);
+					if(__fsqrt_rn(__fmul_rn(f, r)) >= ident_thr){                // pcr_assay.cpp:572-576
+						uint64_t *dst = (orient == 0) ? bits_fr : bits_rf;
+						atomicOr((unsigned long long *)&dst[(size_t)pair*bit_words + (ei.seq >> 6)], 1ull << (ei.seq & 63));
+					}
+				}
+			}
+		}
+	}
+}
+
+// ============================================================================== host state
+template<class T> struct DevBuf {
+	T *p = nullptr; size_t cap = 0;
+	int ensure(size_t n)
+	{
+		if(n <= cap) return PCR_OK;
+		if(p){ (void)hipFree(p); p = nullptr; cap = 0; }
+		const size_t want = std::max<size_t>(n, 16);
+		hipError_t e = hipMalloc((void **)&p, want*sizeof(T));
+		if(e != hipSuccess){ g_err = std::string("hipMalloc: ") + hipGetErrorString(e); return PCR_ERR_DEVICE; }
+		cap = want;
+		return PCR_OK;
+	}
+	void release() { if(p){ (void)hipFree(p); p = nullptr; cap = 0; } }
+};
+
+struct SeqSet {
+	uint32_t n = 0;
+	std::vector<std::vector<uint8_t> > packed;   // host copy (split_sequence, irregular re-derivation)
+	std::vector<uint64_t> len, blk_off, nblk_real;
+	std::vector<float> weight;
+	std::vector<uint8_t> active;
+	std::vector<std::vector<pcrhost::IrrEntry> > irr_host;
+	uint64_t total_blocks = 0;
+	uint32_t n_tiles = 0, n_irr = 0;
+	DevBuf<uint4> planes;
+	DevBuf<uint32_t> valid, blk_seq, tile_seq, tile_pos0, irr_off, seg_lo, seg_hi;
+	DevBuf<uint64_t> d_len, d_blk_off, d_nblk_real;
+	DevBuf<uint8_t> d_active;
+	DevBuf<IrrDev> irr;
+	// word DB of the last select
+	bool have_db = false;
+	uint32_t n_entries = 0;
+	DevBuf<DevEntry> db;
+	void release()
+	{
+		planes.release(); valid.release(); blk_seq.release(); tile_seq.release(); tile_pos0.release();
+		irr_off.release(); seg_lo.release(); seg_hi.release(); d_len.release(); d_blk_off.release();
+		d_nblk_real.release(); d_active.release(); irr.release(); db.release();
+	}
+};
+
+} // namespace
+
+struct pcr_ctx {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	bool own_stream = false;
+	pcr_params params;
+	pcrhost::PackFilter filt;
+	SeqSet sets[2];
+	// scratch
+	DevBuf<uint4> cand_fwd, cand_rc;
+	DevBuf<uint32_t> cand_floor, best, counters, mask, status;
+	DevBuf<Hit> hits;
+	DevBuf<uint64_t> keys, keys_sorted, keys_unique, bits_fr, bits_rf;
+	DevBuf<uint8_t> cub_tmp;
+	DevBuf<uint32_t> n_unique;
+	DevBuf<OligoDev> oligos;
+	size_t hit_cap = size_t(1) << 22;
+	// profiling
+	bool prof = false;
+	std::vector<std::pair<hipEvent_t, hipEvent_t> > prof_events;
+	double prof_ms = 0.0; uint64_t prof_launches = 0;
+};
+
+namespace {
+
+int upload_irregular(pcr_ctx *ctx, SeqSet &S)
+{
+	std::vector<IrrDev> flat;
+	std::vector<uint32_t> off(S.n + 1, 0);
+	for(uint32_t s = 0;s < S.n;++s){
+		off[s] = (uint32_t)flat.size();
+		for(size_t k = 0;k < S.irr_host[s].size();++k){
+			const pcrhost::IrrEntry &e = S.irr_host[s][k];
+			IrrDev d;
+			d.w = e.w; d.loc = e.loc; d.seq = s;
+			d.meta = (uint32_t)e.strand | ((uint32_t)e.cws << 8) | ((uint32_t)e.ord << 16);
+			d.local_id = (uint32_t)k;
+			flat.push_back(d);
+		}
+	}
+	off[S.n] = (uint32_t)flat.size();
+	S.n_irr = (uint32_t)flat.size();
+	int rc;
+	if((rc = S.irr.ensure(flat.size())) != PCR_OK) return rc;
+	if((rc = S.irr_off.ensure(off.size())) != PCR_OK) return rc;
+	if(!flat.empty()) HIP_TRY(hipMemcpyAsync(S.irr.p, flat.data(), flat.size()*sizeof(IrrDev), hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(hipMemcpyAsync(S.irr_off.p, off.data(), off.size()*sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	return PCR_OK;
+}
+
+int run_valid(pcr_ctx *ctx, SeqSet &S, uint64_t first_block, uint64_t n_blocks)
+{
+	if(n_blocks == 0) return PCR_OK;
+	const unsigned threads = 256;
+	const unsigned grid = (unsigned)((n_blocks + threads - 1)/threads);
+	hipLaunchKernelGGL(k_valid, dim3(grid), dim3(threads), 0, ctx->stream, S.planes.p, S.d_blk_off.p, S.blk_seq.p,
+		S.d_nblk_real.p, S.valid.p, S.total_blocks, ctx->filt.max_degen, ctx->filt.gc_ok, first_block, n_blocks);
+	HIP_TRY(hipGetLastError());
+	return PCR_OK;
+}
+
+void fill_oligo(OligoDev &o, const uint64_t w[2], float thr2)
+{
+	o.m = pcrhost::planes_of_word(w);
+	const unsigned size = (unsigned)pcrhost::planes_size(o.m);
+	o.floor2 = (unsigned)((float)size*thr2);                                     // optimize.cpp:293
+	o.norm = (size > 0) ? (float)(1.0/size) : 0.0f;                              // optimize.cpp:221
+	o.start = pcrhost::planes_start(o.m);
+	o.stop = pcrhost::planes_stop(o.m);
+	o.p1 = (o.stop >= 1) ? pcrhost::planes_nibble(o.m, o.stop - 1) : 0;
+	o.p2 = (o.stop >= 0) ? pcrhost::planes_nibble(o.m, o.stop) : 0;
+}
+
+int amplify_launch(pcr_ctx *ctx, SeqSet &S, const pcr_pair *pairs, uint32_t n_pairs, const pcr_amplify_args *a,
+	uint64_t *d_fr, uint64_t *d_rf)
+{
+	if(!S.have_db){ g_err = "pcr_amplify: no word DB (call pcr_select_words first)"; return PCR_ERR_STATE; }
+	const uint64_t words = (S.n + 63)/64;
+	HIP_TRY(hipMemsetAsync(d_fr, 0, (size_t)n_pairs*words*sizeof(uint64_t), ctx->stream));
+	HIP_TRY(hipMemsetAsync(d_rf, 0, (size_t)n_pairs*words*sizeof(uint64_t), ctx->stream));
+	if(S.n_entries == 0 || n_pairs == 0) return PCR_OK;
+	const float thr2 = a->collect_threshold*a->collect_threshold;                // pcr_assay.cpp:31-32
+	std::vector<OligoDev> ol(2*(size_t)n_pairs);
+	for(uint32_t i = 0;i < n_pairs;++i){
+		fill_oligo(ol[2*i], pairs[i].f.w, thr2);
+		fill_oligo(ol[2*i + 1], pairs[i].r.w, thr2);
+	}
+	int rc;
+	if((rc = ctx->oligos.ensure(ol.size())) != PCR_OK) return rc;
+	HIP_TRY(hipMemcpyAsync(ctx->oligos.p, ol.data(), ol.size()*sizeof(OligoDev), hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));   // `ol` is a stack-lifetime staging buffer
+	const uint32_t mask_words = (2*n_pairs + 31)/32;
+	if((rc = ctx->mask.ensure((size_t)S.n_entries*mask_words)) != PCR_OK) return rc;
+	if((rc = ctx->status.ensure(1)) != PCR_OK) return rc;
+	HIP_TRY(hipMemsetAsync(ctx->status.p, 0, sizeof(uint32_t), ctx->stream));
+	const unsigned threads = 128;
+	const unsigned grid = (S.n_entries + threads - 1)/threads;
+	hipLaunchKernelGGL(k_match, dim3(grid), dim3(threads), 0, ctx->stream, S.db.p, S.n_entries, ctx->oligos.p,
+		2*n_pairs, mask_words, ctx->mask.p);
+	HIP_TRY(hipGetLastError());
+	hipLaunchKernelGGL(k_pair, dim3(grid), dim3(threads), 0, ctx->stream, S.db.p, S.n_entries, S.seg_hi.p, ctx->mask.p,
+		mask_words, ctx->oligos.p, n_pairs, S.planes.p, S.d_blk_off.p, S.d_len.p, S.d_active.p, a->amp_min, a->amp_max,
+		a->ident_threshold, a->use_taq_mama, d_fr, d_rf, words, ctx->status.p);
+	HIP_TRY(hipGetLastError());
+	return PCR_OK;
+}
+
+} // namespace
+
+// ============================================================================== C-ABI
+extern "C" {
+
+const char *pcr_last_error(void) { return g_err.c_str(); }
+
+pcr_ctx *pcr_create(int device, void *hip_stream, const pcr_params *params)
+{
+	int count = 0;
+	if(hipGetDeviceCount(&count) != hipSuccess || count <= 0){
+		g_err = "pcr_create: no HIP device available (this library has no CPU fallback)";
+		return nullptr;
+	}
+	if(device < 0 || device >= count){ g_err = "pcr_create: bad device index"; return nullptr; }
+	if(hipSetDevice(device) != hipSuccess){ g_err = "pcr_create: hipSetDevice failed"; return nullptr; }
+	hipDeviceProp_t prop;
+	if(hipGetDeviceProperties(&prop, device) != hipSuccess){ g_err = "pcr_create: hipGetDeviceProperties failed"; return nullptr; }
+	if(std::string(prop.gcnArchName).find("gfx950") == std::string::npos){
+		g_err = std::string("pcr_create: device is ") + prop.gcnArchName + ", this build targets gfx950 only";
+		return nullptr;
+	}
+	pcr_ctx *ctx = new pcr_ctx();
+	ctx->device = device;
+	if(hip_stream){ ctx->stream = (hipStream_t)hip_stream; ctx->own_stream = false; }
+	else{
+		if(hipStreamCreate(&ctx->stream) != hipSuccess){ g_err = "pcr_create: hipStreamCreate failed"; delete ctx; return nullptr; }
+		ctx->own_stream = true;
+	}
+	if(params){ ctx->params = *params; }
+	else{ ctx->params.pack_max_degen = 256; ctx->params.pack_min_gc = 0.0f; ctx->params.pack_max_gc = 1.0f; }
+	ctx->filt.max_degen = ctx->params.pack_max_degen;
+	ctx->filt.set_gc(ctx->params.pack_min_gc, ctx->params.pack_max_gc);
+	if(hipMemcpyToSymbol(HIP_SYMBOL(c_taq_mama), h_taq_mama, sizeof(h_taq_mama)) != hipSuccess){
+		g_err = "pcr_create: hipMemcpyToSymbol failed"; delete ctx; return nullptr;
+	}
+	return ctx;
+}
+
+void pcr_destroy(pcr_ctx *ctx)
+{
+	if(!ctx) return;
+	(void)hipSetDevice(ctx->device);
+	(void)hipStreamSynchronize(ctx->stream);
+	for(auto &pr : ctx->prof_events){ (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+	for(int s = 0;s < 2;++s) ctx->sets[s].release();
+	ctx->cand_fwd.release(); ctx->cand_rc.release(); ctx->cand_floor.release(); ctx->best.release();
+	ctx->counters.release(); ctx->mask.release(); ctx->status.release(); ctx->hits.release(); ctx->keys.release();
+	ctx->keys_sorted.release(); ctx->keys_unique.release(); ctx->bits_fr.release(); ctx->bits_rf.release();
+	ctx->cub_tmp.release(); ctx->n_unique.release(); ctx->oligos.release();
+	if(ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+	delete ctx;
+}
+
+uint32_t pcr_num_sequences(pcr_ctx *ctx, pcr_set which) { return ctx ? ctx->sets[which].n : 0; }
+uint64_t pcr_bitset_words(pcr_ctx *ctx, pcr_set which) { return ctx ? (ctx->sets[which].n + 63)/64 : 0; }
+
+int pcr_synchronize(pcr_ctx *ctx)
+{
+	if(!ctx){ g_err = "null ctx"; return PCR_ERR_ARG; }
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	return PCR_OK;
+}
+
+int pcr_load_sequences(pcr_ctx *ctx, pcr_set which, const uint8_t *packed4, const uint64_t *byte_offsets,
+	const uint64_t *lengths, const float *weights, uint32_t n)
+{
+	if(!ctx || (which != PCR_SET_TARGET && which != PCR_SET_BACKGROUND) || (n && (!packed4 || !byte_offsets || !lengths))){
+		g_err = "pcr_load_sequences: bad argument"; return PCR_ERR_ARG;
+	}
+	if(n >= (1u << 24)){ g_err = "pcr_load_sequences: at most 2^24-1 sequences per GPU shard"; return PCR_ERR_CAPACITY; }
+	HIP_TRY(hipSetDevice(ctx->device));
+	SeqSet &S = ctx->sets[which];
+	S.have_db = false; S.n_entries = 0;
+	S.n = n;
+	S.packed.assign(n, std::vector<uint8_t>());
+	S.len.assign(lengths, lengths + n);
+	S.weight.assign(n, 1.0f);
+	if(weights) S.weight.assign(weights, weights + n);
+	S.active.assign(n, 1);
+	S.blk_off.assign(n + 1, 0);
+	S.nblk_real.assign(n, 0);
+	S.irr_host.assign(n, std::vector<pcrhost::IrrEntry>());
+	uint64_t total_bytes = 0, total_blocks = 0, n_tiles = 0;
+	std::vector<uint64_t> dev_byte_off(n);
+	for(uint32_t s = 0;s < n;++s){
+		if(lengths[s] >= (uint64_t(1) << 31)){ g_err = "pcr_load_sequences: sequence longer than 2^31-1 bases"; return PCR_ERR_CAPACITY; }
+		const uint64_t nb = (lengths[s] + 1)/2;
+		S.packed[s].assign(packed4 + byte_offsets[s], packed4 + byte_offsets[s] + nb);
+		if((lengths[s] & 1) && nb) S.packed[s][nb - 1] &= 0xF0;                  // pad nibble = EOS (sequence.cpp:21)
+		dev_byte_off[s] = total_bytes;
+		total_bytes += nb;
+		S.blk_off[s] = total_blocks;
+		S.nblk_real[s] = (lengths[s] + 31)/32;
+		total_blocks += S.nblk_real[s] + 2;
+		if(lengths[s] >= 32) n_tiles += (lengths[s] - 31 + TILE_POS - 1)/TILE_POS;
+	}
+	S.blk_off[n] = total_blocks;
+	S.total_blocks = total_blocks;
+	if(n_tiles >= (uint64_t(1) << 31)){ g_err = "pcr_load_sequences: too many tiles"; return PCR_ERR_CAPACITY; }
+	S.n_tiles = (uint32_t)n_tiles;
+
+	// host-side index pieces: block -> sequence map, tile list, irregular words
+	std::vector<uint32_t> blk_seq(total_blocks), tile_seq(n_tiles), tile_pos0(n_tiles);
+	uint64_t t = 0;
+	for(uint32_t s = 0;s < n;++s){
+		for(uint64_t b = S.blk_off[s];b < S.blk_off[s + 1];++b) blk_seq[b] = s;
+		if(lengths[s] >= 32){
+			const uint64_t nt = (lengths[s] - 31 + TILE_POS - 1)/TILE_POS;
+			for(uint64_t k = 0;k < nt;++k, ++t){ tile_seq[t] = s; tile_pos0[t] = (uint32_t)(k*TILE_POS); }
+		}
+		pcrhost::PackedSeq q; q.buf = S.packed[s].data(); q.len = lengths[s];
+		if(!pcrhost::irregular_words(q, ctx->filt, S.irr_host[s])){
+			g_err = "pcr_load_sequences: more than 64 irregular words share one (loc, strand)"; return PCR_ERR_CAPACITY;
+		}
+	}
+
+	int rc;
+	DevBuf<uint8_t> d_packed; DevBuf<uint64_t> d_byte_off;
+	if((rc = d_packed.ensure(total_bytes)) != PCR_OK) return rc;
+	if((rc = d_byte_off.ensure(n)) != PCR_OK){ d_packed.release(); return rc; }
+	auto fail = [&](int code){ d_packed.release(); d_byte_off.release(); return code; };
+	if((rc = S.planes.ensure(total_blocks)) != PCR_OK) return fail(rc);
+	if((rc = S.valid.ensure(total_blocks)) != PCR_OK) return fail(rc);
+	if((rc = S.blk_seq.ensure(total_blocks)) != PCR_OK) return fail(rc);
+	if((rc = S.tile_seq.ensure(n_tiles)) != PCR_OK) return fail(rc);
+	if((rc = S.tile_pos0.ensure(n_tiles)) != PCR_OK) return fail(rc);
+	if((rc = S.d_len.ensure(n)) != PCR_OK) return fail(rc);
+	if((rc = S.d_blk_off.ensure(n + 1)) != PCR_OK) return fail(rc);
+	if((rc = S.d_nblk_real.ensure(n)) != PCR_OK) return fail(rc);
+	if((rc = S.d_active.ensure(n)) != PCR_OK) return fail(rc);
+	if((rc = S.seg_lo.ensure(n)) != PCR_OK) return fail(rc);
+	if((rc = S.seg_hi.ensure(n)) != PCR_OK) return fail(rc);
+#define H2D(dst, src, bytes) do{ if((bytes) > 0){ hipError_t e_ = hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice); \
+	if(e_ != hipSuccess){ g_err = std::string("hipMemcpy: ") + hipGetErrorString(e_); return fail(PCR_ERR_DEVICE); } } }while(0)
+	for(uint32_t s = 0;s < n;++s) H2D(d_packed.p + dev_byte_off[s], S.packed[s].data(), S.packed[s].size());
+	H2D(d_byte_off.p, dev_byte_off.data(), n*sizeof(uint64_t));
+	H2D(S.blk_seq.p, blk_seq.data(), total_blocks*sizeof(uint32_t));
+	H2D(S.tile_seq.p, tile_seq.data(), n_tiles*sizeof(uint32_t));
+	H2D(S.tile_pos0.p, tile_pos0.data(), n_tiles*sizeof(uint32_t));
+	H2D(S.d_len.p, S.len.data(), n*sizeof(uint64_t));
+	H2D(S.d_blk_off.p, S.blk_off.data(), (n + 1)*sizeof(uint64_t));
+	H2D(S.d_nblk_real.p, S.nblk_real.data(), n*sizeof(uint64_t));
+	H2D(S.d_active.p, S.active.data(), n);
+#undef H2D
+	if(total_blocks){
+		const unsigned threads = 256;
+		const unsigned grid = (unsigned)((total_blocks + threads - 1)/threads);
+		hipLaunchKernelGGL(k_transpose, dim3(grid), dim3(threads), 0, ctx->stream, d_packed.p, d_byte_off.p, S.d_len.p,
+			S.d_blk_off.p, S.blk_seq.p, S.planes.p, total_blocks);
+		if(hipGetLastError() != hipSuccess){ g_err = "k_transpose launch failed"; return fail(PCR_ERR_DEVICE); }
+		if((rc = run_valid(ctx, S, 0, total_blocks)) != PCR_OK) return fail(rc);
+	}
+	if(hipStreamSynchronize(ctx->stream) != hipSuccess){ g_err = "load: stream sync failed"; return fail(PCR_ERR_DEVICE); }
+	d_packed.release(); d_byte_off.release();
+	return upload_irregular(ctx, S);
+}
+
+int pcr_set_active(pcr_ctx *ctx, pcr_set which, const uint8_t *active)
+{
+	if(!ctx || !active){ g_err = "pcr_set_active: bad argument"; return PCR_ERR_ARG; }
+	SeqSet &S = ctx->sets[which];
+	for(uint32_t i = 0;i < S.n;++i) S.active[i] = active[i] ? 1 : 0;
+	if(S.n){
+		HIP_TRY(hipMemcpyAsync(S.d_active.p, S.active.data(), S.n, hipMemcpyHostToDevice, ctx->stream));
+		HIP_TRY(hipStreamSynchronize(ctx->stream));
+	}
+	return PCR_OK;
+}
+
+int pcr_split(pcr_ctx *ctx, pcr_set which, uint32_t seq, uint64_t pos)
+{
+	if(!ctx){ g_err = "null ctx"; return PCR_ERR_ARG; }
+	SeqSet &S = ctx->sets[which];
+	if(seq >= S.n || pos >= S.len[seq]){ g_err = "pcr_split: out of range"; return PCR_ERR_ARG; }
+	uint8_t &v = S.packed[seq][pos >> 1];
+	v = (pos & 1) ? (v & 0xF0) : (v & 0x0F);                                     // sequence.h:232-241
+	// device: clear the base in its block, refresh the 2 blocks of windows that can see it, redo the irregular list
+	const uint64_t gb = S.blk_off[seq] + (pos >> 5);
+	uint4 blk;
+	HIP_TRY(hipMemcpy(&blk, S.planes.p + gb, sizeof(uint4), hipMemcpyDeviceToHost));
+	const uint32_t m = ~(1u << (pos & 31));
+	blk.x &= m; blk.y &= m; blk.z &= m; blk.w &= m;
+	HIP_TRY(hipMemcpy(S.planes.p + gb, &blk, sizeof(uint4), hipMemcpyHostToDevice));
+	const uint64_t first = (gb > S.blk_off[seq]) ? gb - 1 : gb;
+	int rc = run_valid(ctx, S, first, gb - first + 1);
+	if(rc != PCR_OK) return rc;
+	S.irr_host[seq].clear();
+	pcrhost::PackedSeq q; q.buf = S.packed[seq].data(); q.len = S.len[seq];
+	if(!pcrhost::irregular_words(q, ctx->filt, S.irr_host[seq])){ g_err = "pcr_split: irregular word overflow"; return PCR_ERR_CAPACITY; }
+	S.have_db = false;
+	return upload_irregular(ctx, S);
+}
+
+int pcr_select_words(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_pairs, int optimize_5, int optimize_3,
+	float threshold, uint32_t min_oligo_length, uint64_t *n_entries_out)
+{
+	if(!ctx || (n_pairs && !pairs)){ g_err = "pcr_select_words: bad argument"; return PCR_ERR_ARG; }
+	if(min_oligo_length < 1 || min_oligo_length > 32){ g_err = "pcr_select_words: min_oligo_length must be in [1,32]"; return PCR_ERR_ARG; }
+	HIP_TRY(hipSetDevice(ctx->device));
+	SeqSet &S = ctx->sets[which];
+	S.have_db = false; S.n_entries = 0;
+	if(n_entries_out) *n_entries_out = 0;
+	std::vector<pcrhost::Candidate> cand;
+	pcrhost::build_candidates((const uint64_t *)pairs, n_pairs, optimize_5 != 0, optimize_3 != 0, threshold, cand);
+	const uint32_t ncand = (uint32_t)cand.size();
+	if(S.n == 0 || ncand == 0){ S.have_db = true; return PCR_OK; }
+	std::vector<uint4> hf(ncand), hr(ncand); std::vector<uint32_t> hfl(ncand);
+	for(uint32_t c = 0;c < ncand;++c){
+		hf[c] = make_uint4(cand[c].fwd.a, cand[c].fwd.c, cand[c].fwd.g, cand[c].fwd.t);
+		hr[c] = make_uint4(cand[c].rc.a, cand[c].rc.c, cand[c].rc.g, cand[c].rc.t);
+		hfl[c] = cand[c].floor_;
+	}
+	int rc;
+	if((rc = ctx->cand_fwd.ensure(ncand)) != PCR_OK) return rc;
+	if((rc = ctx->cand_rc.ensure(ncand)) != PCR_OK) return rc;
+	if((rc = ctx->cand_floor.ensure(ncand)) != PCR_OK) return rc;
+	if((rc = ctx->best.ensure((size_t)S.n*ncand)) != PCR_OK) return rc;
+	if((rc = ctx->counters.ensure(4)) != PCR_OK) return rc;
+	HIP_TRY(hipMemcpyAsync(ctx->cand_fwd.p, hf.data(), ncand*sizeof(uint4), hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(hipMemcpyAsync(ctx->cand_rc.p, hr.data(), ncand*sizeof(uint4), hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(hipMemcpyAsync(ctx->cand_floor.p, hfl.data(), ncand*sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+
+	uint32_t h_counters[4];
+	for(int attempt = 0;;++attempt){
+		if((rc = ctx->hits.ensure(ctx->hit_cap)) != PCR_OK) return rc;
+		if((rc = ctx->keys.ensure(ctx->hit_cap)) != PCR_OK) return rc;
+		HIP_TRY(hipMemsetAsync(ctx->best.p, 0, (size_t)S.n*ncand*sizeof(uint32_t), ctx->stream));
+		HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, 4*sizeof(uint32_t), ctx->stream));
+		if(S.n_tiles){
+			hipEvent_t e0 = nullptr, e1 = nullptr;
+			if(ctx->prof){
+				HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+				HIP_TRY(hipEventRecord(e0, ctx->stream));
+			}
+			hipLaunchKernelGGL(k_scan, dim3(S.n_tiles), dim3(SCAN_THREADS), 0, ctx->stream, S.planes.p, S.valid.p,
+				S.d_blk_off.p, S.d_len.p, S.d_active.p, S.tile_seq.p, S.tile_pos0.p, ctx->cand_fwd.p, ctx->cand_rc.p,
+				ctx->cand_floor.p, ncand, ctx->best.p, ctx->hits.p, ctx->counters.p, (uint32_t)ctx->hit_cap);
+			HIP_TRY(hipGetLastError());
+			if(ctx->prof){
+				HIP_TRY(hipEventRecord(e1, ctx->stream));
+				ctx->prof_events.push_back(std::make_pair(e0, e1));
+			}
+		}
+		if(S.n_irr){
+			const unsigned threads = 64;
+			hipLaunchKernelGGL(k_scan_irr, dim3((S.n_irr + threads - 1)/threads), dim3(threads), 0, ctx->stream, S.irr.p,
+				S.n_irr, S.d_active.p, min_oligo_length, ctx->cand_fwd.p, ctx->cand_floor.p, ncand, ctx->best.p,
+				ctx->hits.p, ctx->counters.p, (uint32_t)ctx->hit_cap);
+			HIP_TRY(hipGetLastError());
+		}
+		HIP_TRY(hipMemcpyAsync(h_counters, ctx->counters.p, sizeof(h_counters), hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(hipStreamSynchronize(ctx->stream));
+		if(h_counters[0] <= ctx->hit_cap) break;
+		// the hit list overflowed: grow and redo the pass
+		if(attempt >= 6 || (size_t)h_counters[0] > (size_t(1) << 31)){ g_err = "pcr_select_words: hit list does not fit"; return PCR_ERR_CAPACITY; }
+		ctx->hit_cap = std::max<size_t>(ctx->hit_cap*2, (size_t)h_counters[0] + (h_counters[0] >> 2));
+	}
+	const uint32_t n_hits = h_counters[0];
+	uint32_t n_keys = 0, n_unique = 0;
+	if(n_hits){
+		const unsigned threads = 256;
+		hipLaunchKernelGGL(k_filter, dim3((n_hits + threads - 1)/threads), dim3(threads), 0, ctx->stream, ctx->hits.p, n_hits,
+			ctx->best.p, ncand, ctx->keys.p, ctx->counters.p);
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipMemcpyAsync(h_counters, ctx->counters.p, sizeof(h_counters), hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(hipStreamSynchronize(ctx->stream));
+		n_keys = h_counters[1];
+	}
+	if(n_keys){
+		if((rc = ctx->keys_sorted.ensure(n_keys)) != PCR_OK) return rc;
+		if((rc = ctx->keys_unique.ensure(n_keys)) != PCR_OK) return rc;
+		if((rc = ctx->n_unique.ensure(1)) != PCR_OK) return rc;
+		size_t tmp1 = 0, tmp2 = 0;
+		HIP_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp1, ctx->keys.p, ctx->keys_sorted.p, (int)n_keys, 0, 64, ctx->stream));
+		HIP_TRY(hipcub::DeviceSelect::Unique(nullptr, tmp2, ctx->keys_sorted.p, ctx->keys_unique.p, ctx->n_unique.p, (int)n_keys, ctx->stream));
+		size_t tmp = std::max(tmp1, tmp2);
+		if((rc = ctx->cub_tmp.ensure(tmp)) != PCR_OK) return rc;
+		HIP_TRY(hipcub::DeviceRadixSort::SortKeys(ctx->cub_tmp.p, tmp1, ctx->keys.p, ctx->keys_sorted.p, (int)n_keys, 0, 64, ctx->stream));
+		HIP_TRY(hipcub::DeviceSelect::Unique(ctx->cub_tmp.p, tmp2, ctx->keys_sorted.p, ctx->keys_unique.p, ctx->n_unique.p, (int)n_keys, ctx->stream));
+		HIP_TRY(hipMemcpyAsync(&n_unique, ctx->n_unique.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(hipStreamSynchronize(ctx->stream));
+	}
+	HIP_TRY(hipMemsetAsync(S.seg_lo.p, 0, S.n*sizeof(uint32_t), ctx->stream));
+	HIP_TRY(hipMemsetAsync(S.seg_hi.p, 0, S.n*sizeof(uint32_t), ctx->stream));
+	if(n_unique){
+		if((rc = S.db.ensure(n_unique)) != PCR_OK) return rc;
+		const unsigned threads = 256;
+		hipLaunchKernelGGL(k_entries, dim3((n_unique + threads - 1)/threads), dim3(threads), 0, ctx->stream, ctx->keys_unique.p,
+			n_unique, S.planes.p, S.d_blk_off.p, S.irr.p, S.irr_off.p, S.db.p, S.seg_lo.p, S.seg_hi.p);
+		HIP_TRY(hipGetLastError());
+	}
+	S.n_entries = n_unique;
+	S.have_db = true;
+	if(n_entries_out) *n_entries_out = n_unique;
+	return PCR_OK;
+}
+
+int64_t pcr_get_entries(pcr_ctx *ctx, pcr_set which, pcr_entry *out, uint64_t cap)
+{
+	if(!ctx){ g_err = "null ctx"; return PCR_ERR_ARG; }
+	SeqSet &S = ctx->sets[which];
+	if(!S.have_db){ g_err = "pcr_get_entries: no word DB"; return PCR_ERR_STATE; }
+	const uint64_t n = std::min<uint64_t>(cap, S.n_entries);
+	if(n && out){
+		std::vector<DevEntry> h(n);
+		hipError_t e = hipStreamSynchronize(ctx->stream);
+		if(e == hipSuccess) e = hipMemcpy(h.data(), S.db.p, n*sizeof(DevEntry), hipMemcpyDeviceToHost);
+		if(e != hipSuccess){ g_err = std::string("pcr_get_entries: ") + hipGetErrorString(e); return PCR_ERR_DEVICE; }
+		for(uint64_t i = 0;i < n;++i){
+			pcrhost::word_of_planes(h[i].w, out[i].word.w);
+			out[i].loc = h[i].loc; out[i].index = h[i].seq; out[i].strand = h[i].strand; out[i].pad = 0;
+		}
+	}
+	return (int64_t)S.n_entries;
+}
+
+int pcr_amplify_device(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_pairs, const pcr_amplify_args *args,
+	uint64_t *d_bits_fr, uint64_t *d_bits_rf)
+{
+	if(!ctx || !args || (n_pairs && (!pairs || !d_bits_fr || !d_bits_rf))){ g_err = "pcr_amplify_device: bad argument"; return PCR_ERR_ARG; }
+	HIP_TRY(hipSetDevice(ctx->device));
+	return amplify_launch(ctx, ctx->sets[which], pairs, n_pairs, args, d_bits_fr, d_bits_rf);
+}
+
+int pcr_amplify(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_pairs, const pcr_amplify_args *args,
+	uint64_t *bits, uint64_t *bits_fr, uint64_t *bits_rf, float *coverage)
+{
+	if(!ctx || !args || (n_pairs && !pairs)){ g_err = "pcr_amplify: bad argument"; return PCR_ERR_ARG; }
+	HIP_TRY(hipSetDevice(ctx->device));
+	SeqSet &S = ctx->sets[which];
+	const uint64_t words = (S.n + 63)/64;
+	const size_t total = (size_t)n_pairs*words;
+	int rc;
+	if((rc = ctx->bits_fr.ensure(total)) != PCR_OK) return rc;
+	if((rc = ctx->bits_rf.ensure(total)) != PCR_OK) return rc;
+	if((rc = amplify_launch(ctx, S, pairs, n_pairs, args, ctx->bits_fr.p, ctx->bits_rf.p)) != PCR_OK) return rc;
+	std::vector<uint64_t> hfr(total), hrf(total);
+	uint32_t status = 0;
+	if(total){
+		HIP_TRY(hipMemcpyAsync(hfr.data(), ctx->bits_fr.p, total*sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(hipMemcpyAsync(hrf.data(), ctx->bits_rf.p, total*sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+	}
+	if(ctx->status.p && S.n_entries && n_pairs) HIP_TRY(hipMemcpyAsync(&status, ctx->status.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	if(status & 1u){ g_err = "Sequence::has_split: range is out of bounds"; return PCR_ERR_RANGE; }   // sequence.cpp:306-308
+	for(uint32_t p = 0;p < n_pairs;++p){
+		if(bits){ for(uint64_t w = 0;w < words;++w) bits[p*words + w] = hfr[p*words + w] | hrf[p*words + w]; }
+		if(bits_fr) memcpy(bits_fr + p*words, hfr.data() + p*words, words*sizeof(uint64_t));
+		if(bits_rf) memcpy(bits_rf + p*words, hrf.data() + p*words, words*sizeof(uint64_t));
+		if(coverage) coverage[p] = pcr_coverage_from_bits(hfr.data() + p*words, hrf.data() + p*words, S.weight.data(), S.n);
+	}
+	return PCR_OK;
+}
+
+float pcr_coverage_from_bits(const uint64_t *bits_fr, const uint64_t *bits_rf, const float *weights, uint64_t n)
+{
+	// PCR::compute_coverage (pcr_assay.cpp:271-302): amplicons are visited {F(+),R(-)} first in
+	// ascending sequence order, then {R(+),F(-)}; each sequence's weight is added once, in double.
+	double ret = 0.0;
+	for(uint64_t i = 0;i < n;++i){ if((bits_fr[i >> 6] >> (i & 63)) & 1) ret += weights[i]; }
+	for(uint64_t i = 0;i < n;++i){
+		if(((bits_rf[i >> 6] >> (i & 63)) & 1) && !((bits_fr[i >> 6] >> (i & 63)) & 1)) ret += weights[i];
+	}
+	return (float)ret;
+}
+
+float pcr_weighted_coverage(const uint64_t *bits, const float *weights, uint64_t n)
+{
+	double ret = 0.0;                                                            // main.cpp:1402-1418
+	for(uint64_t i = 0;i < n;++i){ if((bits[i >> 6] >> (i & 63)) & 1) ret += weights[i]; }
+	return (float)ret;
+}
+
+int pcr_profile_enable(pcr_ctx *ctx, int on)
+{
+	if(!ctx){ g_err = "null ctx"; return PCR_ERR_ARG; }
+	ctx->prof = (on != 0);
+	return PCR_OK;
+}
+
+int pcr_profile_read(pcr_ctx *ctx, double *scan_ms, uint64_t *scan_launches, int reset)
+{
+	if(!ctx){ g_err = "null ctx"; return PCR_ERR_ARG; }
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	for(auto &pr : ctx->prof_events){
+		float ms = 0.0f;
+		HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
+		ctx->prof_ms += ms; ctx->prof_launches += 1;
+		(void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second);
+	}
+	ctx->prof_events.clear();
+	if(scan_ms) *scan_ms = ctx->prof_ms;
+	if(scan_launches) *scan_launches = ctx->prof_launches;
+	if(reset){ ctx->prof_ms = 0.0; ctx->prof_launches = 0; }
+	return PCR_OK;
+}
+
+// ------------------------------------------------------------------ host-only helpers
+static pcrhost::PackFilter make_filter(const pcr_params *params)
+{
+	pcrhost::PackFilter f;
+	f.max_degen = params ? params->pack_max_degen : 256;
+	f.set_gc(params ? params->pack_min_gc : 0.0f, params ? params->pack_max_gc : 1.0f);
+	return f;
+}
+
+int64_t pcr_host_irregular_words(const uint8_t *packed4, uint64_t len, const pcr_params *params,
+	uint32_t min_oligo_length, pcr_entry *out, uint64_t cap)
+{
+	if(len && !packed4){ g_err = "pcr_host_irregular_words: bad argument"; return PCR_ERR_ARG; }
+	std::vector<uint8_t> buf(packed4, packed4 + (len + 1)/2);
+	if((len & 1) && !buf.empty()) buf.back() &= 0xF0;
+	const pcrhost::PackFilter f = make_filter(params);
+	std::vector<pcrhost::IrrEntry> v;
+	pcrhost::PackedSeq q; q.buf = buf.data(); q.len = len;
+	if(!pcrhost::irregular_words(q, f, v)){ g_err = "irregular word overflow"; return PCR_ERR_CAPACITY; }
+	uint64_t n = 0;
+	for(const pcrhost::IrrEntry &e : v){
+		if(e.cws < min_oligo_length) continue;
+		if(n < cap && out){
+			pcrhost::word_of_planes(e.w, out[n].word.w);
+			out[n].loc = e.loc; out[n].index = 0; out[n].strand = e.strand; out[n].pad = e.ord;
+		}
+		++n;
+	}
+	return (int64_t)n;
+}
+
+int pcr_host_window_valid(const uint8_t *packed4, uint64_t len, const pcr_params *params, uint8_t *valid_out)
+{
+	if(len && (!packed4 || !valid_out)){ g_err = "pcr_host_window_valid: bad argument"; return PCR_ERR_ARG; }
+	const pcrhost::PackFilter f = make_filter(params);
+	pcrhost::PackedSeq q; q.buf = packed4; q.len = len;
+	for(uint64_t p = 0;p < len;++p){
+		bool ok = (p + 32 <= len);
+		unsigned n2 = 0, n3 = 0, n4 = 0, ngc = 0;
+		for(int k = 0;ok && k < 32;++k){
+			const unsigned v = q.at(p + k);
+			if(v == 0){ ok = false; break; }
+			const int d = __builtin_popcount(v);
+			n2 += (d == 2); n3 += (d == 3); n4 += (d == 4);
+			ngc += ((v & 6) != 0);
+		}
+		if(ok && !((f.gc_ok >> ngc) & 1)) ok = false;
+		if(ok && pcrhost::degeneracy_exceeds(n2, n3, n4, f.max_degen)) ok = false;
+		valid_out[p] = ok ? 1 : 0;
+	}
+	return PCR_OK;
+}
+
+int64_t pcr_host_candidates(const pcr_pair *pairs, uint32_t n_pairs, int optimize_5, int optimize_3,
+	float threshold, pcr_word128 *words_out, uint32_t *floors_out, uint64_t cap)
+{
+	std::vector<pcrhost::Candidate> cand;
+	pcrhost::build_candidates((const uint64_t *)pairs, n_pairs, optimize_5 != 0, optimize_3 != 0, threshold, cand);
+	for(size_t i = 0;i < cand.size() && i < cap;++i){
+		if(words_out) pcrhost::word_of_planes(cand[i].fwd, words_out[i].w);
+		if(floors_out) floors_out[i] = cand[i].floor_;
+	}
+	return (int64_t)cand.size();
+}
+
+} // extern "C"

@@ -1,0 +1,411 @@
+// Host-side data model of the MI355X evaluation path (plain C++, no HIP).
+//
+// The device never materialises the reference's word index (Sequence::pack, sequence.cpp:92-267
+// emits ~2L (Word, WordMatch) pairs per sequence per design iteration).  Instead a sequence is
+// split into
+//   * REGULAR windows: every start p whose 32 bases p..p+31 are non-EOS.  pack emits exactly one
+//     plus and one minus full word for such a window (sequence.cpp:181-194) unless the window
+//     degeneracy / GC filters skip it (sequence.cpp:127-153).  These are scanned on the GPU straight
+//     from the bit-plane store; and
+//   * IRREGULAR words: everything else pack emits -- the centred partial words at the head
+//     (sequence.cpp:155-179) and tail (sequence.cpp:198-263), and whatever the streaming window
+//     produces within 31 pushes of an EOS nibble.  There are O(32) of them per sequence end / EOS;
+//     they are produced here by running the streaming state machine only over those zones and
+//     are kept as an explicit word list.
+// DESIGN.md "Exactness of the window model" has the argument for why the split is exact.
+#ifndef PCR_HOST_HPP
+#define PCR_HOST_HPP
+
+#include <stdint.h>
+#include <algorithm>
+#include <deque>
+#include <vector>
+
+namespace pcrhost {
+
+// A 32-slot oligo / word as four slot masks: bit k of a = slot k may be 'A', etc.
+// (slot 0 = 5' end).  An EOS slot has no bit in any plane.
+struct Planes {
+	uint32_t a, c, g, t;
+};
+
+inline uint32_t bitrev32(uint32_t v)
+{
+	v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+	v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+	v = ((v >> 4) & 0x0F0F0F0Fu) | ((v & 0x0F0F0F0Fu) << 4);
+	v = ((v >> 8) & 0x00FF00FFu) | ((v & 0x00FF00FFu) << 8);
+	return (v >> 16) | (v << 16);
+}
+
+// Reference Word layout (word.cpp:11-16) <-> slot nibbles.
+inline unsigned word_get(const uint64_t w[2], int k) { return (unsigned)(w[k >> 4] >> ((15 - (k & 15))*4)) & 0xF; }
+
+inline void word_set(uint64_t w[2], int k, unsigned v)
+{
+	const int sh = (15 - (k & 15))*4;
+	w[k >> 4] = (w[k >> 4] & ~(uint64_t(0xF) << sh)) | (uint64_t(v) << sh);
+}
+
+inline Planes planes_of_word(const uint64_t w[2])
+{
+	Planes p = {0, 0, 0, 0};
+	for(int k = 0;k < 32;++k){
+		const unsigned v = word_get(w, k);
+		p.a |= uint32_t(v & 1) << k;
+		p.c |= uint32_t((v >> 1) & 1) << k;
+		p.g |= uint32_t((v >> 2) & 1) << k;
+		p.t |= uint32_t((v >> 3) & 1) << k;
+	}
+	return p;
+}
+
+inline void word_of_planes(const Planes &p, uint64_t w[2])
+{
+	w[0] = w[1] = 0;
+	for(int k = 0;k < 32;++k){
+		const unsigned v = ((p.a >> k) & 1) | (((p.c >> k) & 1) << 1) | (((p.g >> k) & 1) << 2) | (((p.t >> k) & 1) << 3);
+		word_set(w, k, v);
+	}
+}
+
+// The reverse complement in slot space: slot k -> slot 31-k, A<->T, C<->G.  Scanning the plus
+// strand with these masks counts what the reference counts against the minus-strand word
+// Word::complement() of the same window (word.h:140-183, sequence.cpp:188-190).
+inline Planes planes_revcomp(const Planes &p)
+{
+	Planes r;
+	r.a = bitrev32(p.t);
+	r.t = bitrev32(p.a);
+	r.c = bitrev32(p.g);
+	r.g = bitrev32(p.c);
+	return r;
+}
+
+inline uint32_t planes_occupied(const Planes &p) { return p.a | p.c | p.g | p.t; }
+inline int planes_size(const Planes &p) { return __builtin_popcount(planes_occupied(p)); }                 // Word::size, word.cpp:199
+inline int planes_start(const Planes &p) { const uint32_t o = planes_occupied(p); return o ? __builtin_ctz(o) : 32; } // word.h:256
+inline int planes_stop(const Planes &p) { const uint32_t o = planes_occupied(p); return o ? 31 - __builtin_clz(o) : -1; } // word.h:273
+
+inline unsigned planes_nibble(const Planes &p, int k)
+{
+	return ((p.a >> k) & 1) | (((p.c >> k) & 1) << 1) | (((p.g >> k) & 1) << 2) | (((p.t >> k) & 1) << 3);
+}
+
+// Word::shift_left / shift_right (word.cpp:215-231): towards slot 0 / towards slot 31.
+inline Planes planes_shift_left(const Planes &p) { Planes r = {p.a >> 1, p.c >> 1, p.g >> 1, p.t >> 1}; return r; }
+inline Planes planes_shift_right(const Planes &p) { Planes r = {p.a << 1, p.c << 1, p.g << 1, p.t << 1}; return r; }
+
+// ---------------------------------------------------------------------------------------------
+// Window filters of Sequence::pack, evaluated for a full 32-base window.
+struct PackFilter {
+	uint32_t max_degen;   // m_degen_pack_threshold
+	uint64_t gc_ok;       // bit n set <=> a window with n G/C-containing slots passes (all ones if filter off)
+	bool gc_on;
+
+	// sequence.cpp:102-106,127-146: fraction = num_gc * (1.0f/32) compared in float.
+	void set_gc(float min_gc, float max_gc)
+	{
+		gc_on = (min_gc > 0.0f) || (max_gc < 1.0f);
+		gc_ok = 0;
+		const float norm = 1.0f/32;
+		for(unsigned n = 0;n <= 32;++n){
+			const float f = n*norm;
+			const bool skip = gc_on && ((f < min_gc) || (f > max_gc));
+			if(!skip){ gc_ok |= (uint64_t(1) << n); }
+		}
+	}
+};
+
+// Word::degeneracy() > threshold (word.h:97-138, sequence.cpp:149) for a window with n2/n3/n4
+// slots of 2/3/4-fold degeneracy.  The product 2^n2 * 3^n3 * 4^n4 is exact in double (3^32 < 2^53),
+// so the comparison is an exact integer one: 3^n3 * 2^e > thr  <=>  3^n3 > floor(thr / 2^e).
+inline bool degeneracy_exceeds(unsigned n2, unsigned n3, unsigned n4, uint32_t thr)
+{
+	const unsigned e = n2 + 2*n4;
+	if(e >= 33){ return true; }
+	uint64_t p3 = 1;
+	for(unsigned i = 0;i < n3;++i){ p3 *= 3; }
+	return p3 > (uint64_t(thr) >> e);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Irregular words.
+struct IrrEntry {
+	Planes w;        // the DB word exactly as pack stores it (minus-strand words already complemented)
+	int32_t loc;     // WordMatch::loc
+	uint8_t strand;  // 1 plus, 2 minus
+	uint8_t cws;     // the size counter pack compares with m_min_oligo_length (32 = full-word emission)
+	uint8_t ord;     // tie-break among irregular entries sharing (loc, strand) in one sequence
+	uint8_t pad;
+};
+
+struct PackedSeq {
+	const uint8_t *buf;   // high nibble first
+	uint64_t len;         // bases
+	unsigned at(uint64_t i) const
+	{
+		if(i >= len){ return 0; }   // the odd-length pad nibble is EOS (sequence.cpp:21)
+		const uint8_t v = buf[i >> 1];
+		return (i & 1) ? (v & 0xF) : (v >> 4);
+	}
+};
+
+// The streaming window of Sequence::pack (sequence.cpp:92-267) as an explicit state machine
+// over slot nibbles.
+class PackMachine {
+public:
+	PackMachine(const PackFilter &f, std::vector<IrrEntry> &out) : filt(f), dst(out) { reset(); }
+
+	void reset()
+	{
+		for(int k = 0;k < 32;++k){ s[k] = 0; }
+		cws = 0;
+		gc.clear();
+		num_gc = 0;
+	}
+
+	// State right after a REGULAR iteration whose window is bases[0..31].
+	void seed_after_regular(const uint8_t bases[32])
+	{
+		for(int k = 0;k < 32;++k){ s[k] = bases[k]; }
+		cws = 31;
+		gc.clear();
+		num_gc = 0;
+		for(int k = 0;k < 32;++k){ gc.push_back(bases[k]); num_gc += ((bases[k] & 6) != 0); }
+	}
+
+	// One loop iteration of sequence.cpp:110-195 with `loc` as the reference counts it (1-based).
+	// `record` = false suppresses the output (used for regular iterations, which the GPU owns).
+	void push(unsigned b, int loc, bool record)
+	{
+		push_back(b);
+		cws += (b != 0);
+		if(filt.gc_on){
+			if(gc.size() == 32){ num_gc -= ((gc.front() & 6) != 0); gc.pop_front(); }
+			gc.push_back((uint8_t)b);
+			num_gc += ((b & 6) != 0);
+			if(!((filt.gc_ok >> num_gc) & 1)){ cws = std::min(cws, 31u); return; }
+		}
+		if(degenerate()){ cws = std::min(cws, 31u); return; }
+		if(cws < 32){
+			if(record){ emit_partial(loc - int(cws), loc - 1); }
+		}
+		else{
+			if(record){
+				uint8_t rc[32];
+				revcomp(s, rc);
+				emit(s, loc - 32, 1, 32);
+				emit(rc, loc - 1, 2, 32);
+			}
+			--cws;
+		}
+	}
+
+	// The trailing loop, sequence.cpp:198-263; `loc` is the loop counter's final value.
+	void drain(int loc)
+	{
+		while(cws > 0){
+			for(int k = 0;k < 31;++k){ s[k] = s[k + 1]; }
+			s[31] = 0;
+			--cws;
+			if(filt.gc_on){
+				if(gc.size() == 32){ num_gc -= ((gc.front() & 6) != 0); gc.pop_front(); }
+				if(!((filt.gc_ok >> num_gc) & 1)){ continue; }
+			}
+			if(degenerate()){ continue; }
+			emit_partial(loc - 1 - int(cws), loc - 2);
+		}
+	}
+
+private:
+	const PackFilter &filt;
+	std::vector<IrrEntry> &dst;
+	uint8_t s[32];
+	unsigned cws;
+	std::deque<uint8_t> gc;
+	unsigned num_gc;
+
+	int start_of(const uint8_t *x) const { for(int k = 0;k < 32;++k){ if(x[k]) return k; } return 32; }
+	int stop_of(const uint8_t *x) const { for(int k = 31;k >= 0;--k){ if(x[k]) return k; } return -1; }
+
+	void push_back(unsigned b)                                                    // word.cpp:31-48
+	{
+		const int last = stop_of(s) + 1;
+		if(last < 32){ s[last] = (uint8_t)b; return; }
+		for(int k = 0;k < 31;++k){ s[k] = s[k + 1]; }
+		s[31] = (uint8_t)b;
+	}
+
+	bool degenerate() const
+	{
+		unsigned n2 = 0, n3 = 0, n4 = 0;
+		for(int k = 0;k < 32;++k){
+			const int d = __builtin_popcount(s[k]);
+			n2 += (d == 2); n3 += (d == 3); n4 += (d == 4);
+		}
+		return degeneracy_exceeds(n2, n3, n4, filt.max_degen);
+	}
+
+	static void center(uint8_t *x)                                                // word.h:392-418
+	{
+		int left = 32, right = -1;
+		for(int k = 0;k < 32;++k){ if(x[k]){ left = k; break; } }
+		for(int k = 31;k >= 0;--k){ if(x[k]){ right = k; break; } }
+		if(left > right){ return; }
+		right = 32 - right;
+		const int delta = (right - left)/2;
+		uint8_t y[32];
+		for(int k = 0;k < 32;++k){
+			const int src = k - delta;
+			y[k] = (src >= 0 && src < 32) ? x[src] : 0;
+		}
+		for(int k = 0;k < 32;++k){ x[k] = y[k]; }
+	}
+
+	void revcomp(const uint8_t *x, uint8_t *y) const                              // word.h:140-183
+	{
+		for(int k = 0;k < 32;++k){ y[k] = 0; }
+		const int first = start_of(x), last = stop_of(x);
+		int d = 0;
+		for(int src = last;src >= first;--src, ++d){
+			const unsigned v = x[src];
+			y[d] = (uint8_t)(((v & 1) << 3) | ((v & 8) >> 3) | ((v & 2) << 1) | ((v & 4) >> 1));
+		}
+	}
+
+	// sequence.cpp:157-178 / 241-255: centre, store plus; complement, re-centre, store minus.
+	void emit_partial(int plus_base, int minus_base)
+	{
+		uint8_t t[32], u[32];
+		for(int k = 0;k < 32;++k){ t[k] = s[k]; }
+		center(t);
+		if(cws >= 1){ emit(t, plus_base - start_of(t), 1, (uint8_t)cws); }
+		revcomp(t, u);
+		center(u);
+		if(cws >= 1){ emit(u, minus_base + start_of(u), 2, (uint8_t)cws); }
+	}
+
+	void emit(const uint8_t *x, int loc, uint8_t strand, uint8_t size_counter)
+	{
+		IrrEntry e;
+		e.w.a = e.w.c = e.w.g = e.w.t = 0;
+		for(int k = 0;k < 32;++k){
+			e.w.a |= uint32_t(x[k] & 1) << k;
+			e.w.c |= uint32_t((x[k] >> 1) & 1) << k;
+			e.w.g |= uint32_t((x[k] >> 2) & 1) << k;
+			e.w.t |= uint32_t((x[k] >> 3) & 1) << k;
+		}
+		e.loc = loc;
+		e.strand = strand;
+		e.cws = size_counter;
+		e.ord = 0;
+		e.pad = 0;
+		dst.push_back(e);
+	}
+};
+
+// All irregular words of one sequence, in emission order, with `ord` filled in.
+// Returns false if a tie-break ordinal would not fit (never seen in practice: > 63 irregular
+// words sharing one (loc, strand)).
+inline bool irregular_words(const PackedSeq &q, const PackFilter &filt, std::vector<IrrEntry> &out)
+{
+	const size_t first_out = out.size();
+	const uint64_t L = q.len;
+	const uint64_t n_iter = (L + 1) & ~uint64_t(1);   // the loop walks whole bytes (sequence.cpp:110-120)
+	if(n_iter == 0){ return true; }
+
+	// Irregular iteration ranges [lo, hi] (0-based iteration = loc - 1): the head, and 32
+	// iterations from every EOS nibble (the pad nibble of an odd-length sequence included).
+	std::vector<std::pair<uint64_t, uint64_t> > zones;
+	zones.push_back(std::make_pair(uint64_t(0), std::min<uint64_t>(30, n_iter - 1)));
+	const uint64_t nbytes = n_iter/2;
+	for(uint64_t byte = 0;byte < nbytes;++byte){
+		const uint8_t v = q.buf[byte];
+		const bool hi_zero = ((v & 0xF0) == 0);
+		const bool lo_zero = ((v & 0x0F) == 0) || (2*byte + 1 >= L);
+		if(!hi_zero && !lo_zero){ continue; }
+		for(int h = 0;h < 2;++h){
+			if(h == 0 ? !hi_zero : !lo_zero){ continue; }
+			const uint64_t e = 2*byte + h;
+			const uint64_t hi = std::min<uint64_t>(e + 31, n_iter - 1);
+			if(!zones.empty() && e <= zones.back().second + 1){ zones.back().second = std::max(zones.back().second, hi); }
+			else{ zones.push_back(std::make_pair(e, hi)); }
+		}
+	}
+
+	PackMachine m(filt, out);
+	bool have_state = false;    // machine state is valid for the iteration following `state_at`
+	uint64_t state_next = 0;
+	for(size_t z = 0;z < zones.size();++z){
+		const uint64_t lo = zones[z].first, hi = zones[z].second;
+		if(lo == 0){ m.reset(); }
+		else if(!(have_state && state_next == lo)){
+			uint8_t bases[32];
+			for(int k = 0;k < 32;++k){ bases[k] = (uint8_t)q.at(lo - 32 + k); }
+			m.seed_after_regular(bases);
+		}
+		for(uint64_t i = lo;i <= hi;++i){ m.push(q.at(i), int(i + 1), true); }
+		have_state = true;
+		state_next = hi + 1;
+	}
+	if(!(have_state && state_next == n_iter)){
+		uint8_t bases[32];
+		for(int k = 0;k < 32;++k){ bases[k] = (uint8_t)q.at(n_iter - 32 + k); }
+		m.seed_after_regular(bases);
+	}
+	m.drain(int(n_iter + 1));
+
+	// tie-break ordinals
+	std::vector<size_t> idx(out.size() - first_out);
+	for(size_t i = 0;i < idx.size();++i){ idx[i] = first_out + i; }
+	std::stable_sort(idx.begin(), idx.end(), [&](size_t x, size_t y){
+		if(out[x].loc != out[y].loc) return out[x].loc < out[y].loc;
+		return out[x].strand < out[y].strand;
+	});
+	for(size_t i = 0;i < idx.size();){
+		size_t j = i;
+		while(j < idx.size() && out[idx[j]].loc == out[idx[i]].loc && out[idx[j]].strand == out[idx[i]].strand){ ++j; }
+		if(j - i > 64){ return false; }
+		for(size_t k = i;k < j;++k){ out[idx[k]].ord = (uint8_t)(k - i); }
+		i = j;
+	}
+	return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Candidate oligo list of select_words (select_words.cpp:22-85): every assay oligo, plus all
+// of its slot shifts towards the 5' end (optimize_5) and towards the 3' end (optimize_3), with
+// the floor unsigned(size * threshold) (select_words.cpp:83: unsigned*float in float, truncated).
+struct Candidate {
+	Planes fwd;      // masks as stored (match against plus-strand windows and irregular words)
+	Planes rc;       // reverse-complemented masks (match against plus-strand windows = minus-strand words)
+	uint32_t floor_;
+};
+
+inline void build_candidates(const uint64_t *pairs /* n x {F[2],R[2]} */, uint32_t n_pairs, bool opt5, bool opt3,
+	float threshold, std::vector<Candidate> &out)
+{
+	for(uint32_t i = 0;i < n_pairs;++i){
+		for(int o = 0;o < 2;++o){
+			const Planes base = planes_of_word(pairs + 4*i + 2*o);
+			std::vector<Planes> v;
+			v.push_back(base);
+			if(opt5 || opt3){
+				const int cs = planes_start(base), ce = planes_stop(base);
+				if(opt5 && cs > 0){ Planes t = base; for(int j = 0;j < cs;++j){ t = planes_shift_left(t); v.push_back(t); } }
+				if(opt3 && ce < 31){ Planes t = base; for(int j = ce;j < 31;++j){ t = planes_shift_right(t); v.push_back(t); } }
+			}
+			for(size_t k = 0;k < v.size();++k){
+				Candidate c;
+				c.fwd = v[k];
+				c.rc = planes_revcomp(v[k]);
+				c.floor_ = (unsigned)((float)(unsigned)planes_size(v[k])*threshold);
+				out.push_back(c);
+			}
+		}
+	}
+}
+
+} // namespace pcrhost
+#endif

@@ -1,0 +1,95 @@
+"""Seeded synthetic workloads with the shapes of BASELINE.json's configs.
+
+Targets come in families: ceil(T/50) random roots, every member a copy of its root with 3 %
+substitutions, so that primers sampled from one target hit many.  Primers are 18-25 nt windows
+of random targets (F) and reverse complements of a downstream window (R), 80-200 bases apart,
+stored centred like the reference's trial assays (pcr_assay.cpp:646,688,719).  Nothing is read
+from disk; everything is a function of (config, seed).
+"""
+import numpy as np
+
+from . import words as W
+
+BASE_SEED = 20240901
+
+CONFIGS = {
+    # name: (T, L, P, n_background, L_background)
+    "C1": dict(T=100, L=1000, P=5),
+    "C2": dict(T=10000, L=10000, P=50),
+    "C3": dict(T=50000, L=2000, P=50, B=10000, LB=2000),
+    "C5_shard": dict(T=12500, L=10000, P=50, degenerate=3),
+}
+
+_ACGT = np.array([1, 2, 4, 8], dtype=np.uint8)
+
+
+def _rng(seed):
+    return np.random.Generator(np.random.MT19937(seed))
+
+
+def make_sequences(T, L, seed, family=50, divergence=0.03, chunk=256):
+    """-> (packed uint8 [sum ceil(L/2)], byte_offsets uint64[T], lengths uint64[T], codes_of(i) callable)."""
+    rng = _rng(seed)
+    n_fam = (T + family - 1) // family
+    roots = _ACGT[rng.integers(0, 4, size=(n_fam, L), dtype=np.uint8)]
+    nb = (L + 1) // 2
+    packed = np.empty(T * nb, dtype=np.uint8)
+    fam_of = np.arange(T) // family
+    for lo in range(0, T, chunk):
+        hi = min(T, lo + chunk)
+        c = roots[fam_of[lo:hi]].copy()
+        mut = rng.random(c.shape, dtype=np.float32) < divergence
+        # a substitution always changes the base: rotate the one-hot code by 1..3 positions
+        rot = rng.integers(1, 4, size=c.shape, dtype=np.uint8)
+        idx = np.log2(c).astype(np.uint8)
+        c = np.where(mut, _ACGT[(idx + rot) & 3], c)
+        if L & 1:
+            c = np.concatenate([c, np.zeros((hi - lo, 1), np.uint8)], axis=1)
+        packed[lo * nb:hi * nb] = ((c[:, 0::2] << 4) | c[:, 1::2]).reshape(-1)
+    byte_offsets = (np.arange(T, dtype=np.uint64) * np.uint64(nb))
+    lengths = np.full(T, L, dtype=np.uint64)
+    return packed, byte_offsets, lengths
+
+
+def sequence_codes(packed, byte_offsets, lengths, i):
+    nb = (int(lengths[i]) + 1) // 2
+    o = int(byte_offsets[i])
+    return W.unpack_codes(packed[o:o + nb], int(lengths[i]))
+
+
+def make_pairs(packed, byte_offsets, lengths, P, seed, primer=(18, 25), amplicon=(80, 200), degenerate=0):
+    """P primer pairs sampled from the sequences; `degenerate` > 0 widens that many positions
+    per primer to a 2-fold IUPAC code (degeneracy <= 2**degenerate)."""
+    rng = _rng(seed ^ 0x5EED)
+    T = len(lengths)
+    pairs = []
+    while len(pairs) < P:
+        t = int(rng.integers(0, T))
+        L = int(lengths[t])
+        fl = int(rng.integers(primer[0], primer[1] + 1))
+        rl = int(rng.integers(primer[0], primer[1] + 1))
+        amp = int(rng.integers(amplicon[0], amplicon[1] + 1))
+        if L < amp or amp < fl + rl:
+            continue
+        fs = int(rng.integers(0, L - amp + 1))
+        codes = sequence_codes(packed, byte_offsets, lengths, t)
+        f = codes[fs:fs + fl].copy()
+        r = W.revcomp_codes(codes[fs + amp - rl:fs + amp]).copy()
+        if (f == 0).any() or (r == 0).any():
+            continue
+        for o in (f, r):
+            for _ in range(degenerate):
+                k = int(rng.integers(0, o.size))
+                o[k] |= _ACGT[int(rng.integers(0, 4))]
+        pairs.append((W.centered_word(f), W.centered_word(r)))
+    return pairs
+
+
+def workload(name, seed_offset=0, scale=1.0):
+    """-> dict(packed, byte_offsets, lengths, pairs, T, L, P).  `scale` < 1 shrinks T (CPU baselines)."""
+    cfg = dict(CONFIGS[name])
+    T = max(1, int(round(cfg["T"] * scale)))
+    seed = BASE_SEED + {"C1": 1, "C2": 2, "C3": 3, "C5_shard": 5}[name] + 1000 * seed_offset
+    packed, off, lens = make_sequences(T, cfg["L"], seed)
+    pairs = make_pairs(packed, off, lens, cfg["P"], seed, degenerate=cfg.get("degenerate", 0))
+    return dict(packed=packed, byte_offsets=off, lengths=lens, pairs=pairs, T=T, L=cfg["L"], P=cfg["P"], name=name)

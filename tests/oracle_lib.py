@@ -1,0 +1,269 @@
+"""ctypes bindings for the two CPU checkers (TEST INFRASTRUCTURE, never used by the product):
+
+* ``Oracle``    -- oracle/liboracle.so, our scalar C++ restatement of the reference path.
+* ``Reference`` -- oracle/_ref/libpcramp_ref.so, the real reference compiled from /root/reference
+                   behind oracle/ref_harness.cpp (only exists where oracle/Makefile could build it).
+
+Both expose the same Python surface so the tests can run one against the other.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+
+
+class Entry(C.Structure):
+    _fields_ = [("w", C.c_uint64 * 2), ("loc", C.c_int32), ("index", C.c_uint32),
+                ("strand", C.c_uint32), ("pad", C.c_uint32)]
+
+
+class OrcOptions(C.Structure):
+    _fields_ = [("target_threshold", C.c_float), ("search_multiplier", C.c_float),
+                ("amp_min", C.c_int32), ("amp_max", C.c_int32), ("use_taq_mama", C.c_int32),
+                ("pack_max_degen", C.c_uint32), ("pack_min_gc", C.c_float), ("pack_max_gc", C.c_float),
+                ("min_primer", C.c_int32), ("optimize_5", C.c_int32), ("optimize_3", C.c_int32)]
+
+
+DEFAULT_OPTIONS = dict(target_threshold=1.0, search_multiplier=0.9, amp_min=80, amp_max=200,
+                       use_taq_mama=0, pack_max_degen=256, pack_min_gc=0.0, pack_max_gc=1.0,
+                       min_primer=18, optimize_5=0, optimize_3=0)
+
+U64x2 = C.c_uint64 * 2
+
+
+def build_oracle():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "liboracle.so"])
+
+
+def build_reference():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "ref"])
+
+
+def _w(x):
+    return U64x2(int(x[0]), int(x[1]))
+
+
+class _Lib:
+    prefix = None
+    path = None
+
+    def __init__(self):
+        self.lib = C.CDLL(self.path)
+        L, p = self.lib, self.prefix
+        f = lambda n: getattr(L, p + n)
+        f("word_and").restype = C.c_uint
+        f("word_size").restype = C.c_uint
+        f("word_degeneracy").restype = C.c_double
+        f("taq_mama").restype = C.c_float
+        f("taq_mama").argtypes = [C.c_uint] * 4
+        f("pack").restype = C.c_long
+        f("pack").argtypes = [C.c_char_p, C.c_uint, C.c_uint, C.c_float, C.c_float, C.c_uint,
+                              C.POINTER(Entry), C.c_long]
+        f("session_create").restype = C.c_void_p
+        f("session_destroy").argtypes = [C.c_void_p]
+        f("session_error").restype = C.c_char_p
+        f("session_error").argtypes = [C.c_void_p]
+        f("session_add_target").argtypes = [C.c_void_p, C.c_char_p, C.c_float, C.c_int]
+        f("session_set_active").argtypes = [C.c_void_p, C.c_uint, C.c_int]
+        f("session_split").argtypes = [C.c_void_p, C.c_uint, C.c_uint]
+        f("session_select").restype = C.c_long
+        f("session_select").argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_float, C.c_int]
+        f("session_db_entries").restype = C.c_long
+        f("session_db_entries").argtypes = [C.c_void_p, C.POINTER(Entry), C.c_long]
+        f("session_target_coverage").restype = C.c_float
+        f("session_target_coverage").argtypes = [C.c_void_p, C.c_void_p]
+        self._f = f
+
+    # ---- words
+    def word(self, s):
+        out = U64x2()
+        if self._f("word_from_string")(s.encode(), out) != 0:
+            raise ValueError("bad word " + s)
+        return (out[0], out[1])
+
+    def word_and(self, a, b):
+        return self._f("word_and")(_w(a), _w(b))
+
+    def word_size(self, a):
+        return self._f("word_size")(_w(a))
+
+    def word_start(self, a):
+        return self._f("word_start")(_w(a))
+
+    def word_stop(self, a):
+        return self._f("word_stop")(_w(a))
+
+    def word_degeneracy(self, a):
+        return self._f("word_degeneracy")(_w(a))
+
+    def word_center(self, a):
+        x = _w(a)
+        self._f("word_center")(x)
+        return (x[0], x[1])
+
+    def word_complement(self, a):
+        o = U64x2()
+        self._f("word_complement")(_w(a), o)
+        return (o[0], o[1])
+
+    def word_shift_left(self, a):
+        x = _w(a)
+        self._f("word_shift_left")(x)
+        return (x[0], x[1])
+
+    def word_shift_right(self, a):
+        x = _w(a)
+        self._f("word_shift_right")(x)
+        return (x[0], x[1])
+
+    def word_expand(self, a, cap=4096):
+        buf = (C.c_uint64 * (2 * cap))()
+        n = self._f("word_expand")(_w(a), buf, cap)
+        return [(buf[2 * i], buf[2 * i + 1]) for i in range(min(n, cap))]
+
+    def centered_word(self, s):
+        return self.word_center(self.word(s))
+
+    def taq_mama(self, p1, p2, t1, t2):
+        return self._f("taq_mama")(p1, p2, t1, t2)
+
+    # ---- pack
+    def pack(self, seq, index=0, degen_thr=256, min_gc=0.0, max_gc=1.0, min_len=18):
+        cap = 2 * len(seq) + 256
+        buf = (Entry * cap)()
+        n = self._f("pack")(seq.encode(), index, degen_thr, min_gc, max_gc, min_len, buf, cap)
+        if n < 0:
+            raise RuntimeError("pack failed")
+        assert n <= cap
+        return sorted((e.w[0], e.w[1], e.loc, e.index, e.strand) for e in buf[:n])
+
+    # ---- session
+    def session(self, **opts):
+        return Session(self, **opts)
+
+
+class Oracle(_Lib):
+    prefix = "orc_"
+    path = os.path.join(ORACLE_DIR, "liboracle.so")
+
+    def __init__(self):
+        if not os.path.exists(self.path):
+            build_oracle()
+        super().__init__()
+        self.lib.orc_session_target_match.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        self.lib.orc_session_add_target_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_float, C.c_int]
+        self.lib.orc_weighted_coverage.restype = C.c_float
+        self.lib.orc_weighted_coverage.argtypes = [C.c_void_p, C.c_void_p]
+
+
+class Reference(_Lib):
+    prefix = "ref_"
+    path = os.path.join(ORACLE_DIR, "_ref", "libpcramp_ref.so")
+
+    def __init__(self):
+        super().__init__()
+        self.lib.ref_session_target_match.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        self.lib.ref_session_set_options.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_int,
+                                                     C.c_int, C.c_uint, C.c_float, C.c_float, C.c_int,
+                                                     C.c_int, C.c_int]
+
+    @classmethod
+    def available(cls):
+        return os.path.exists(cls.path)
+
+
+def pairs_array(pairs):
+    """pairs: list of (F, R) with F, R = (u64, u64) -> contiguous uint64 [n, 4]."""
+    a = np.zeros((len(pairs), 4), dtype=np.uint64)
+    for i, (f, r) in enumerate(pairs):
+        a[i, 0], a[i, 1], a[i, 2], a[i, 3] = f[0], f[1], r[0], r[1]
+    return a
+
+
+class Session:
+    def __init__(self, lib, **opts):
+        self.L = lib
+        self.f = lib._f
+        self.h = self.f("session_create")()
+        self.n = 0
+        self.opts = dict(DEFAULT_OPTIONS)
+        self.set_options(**opts)
+
+    def __del__(self):
+        try:
+            self.f("session_destroy")(self.h)
+        except Exception:
+            pass
+
+    def set_options(self, **opts):
+        self.opts.update(opts)
+        o = self.opts
+        if isinstance(self.L, Oracle):
+            s = OrcOptions(**o)
+            self.f("session_set_options")(C.c_void_p(self.h), C.byref(s))
+        else:
+            self.f("session_set_options")(self.h, o["target_threshold"], o["search_multiplier"],
+                                          o["amp_min"], o["amp_max"], o["use_taq_mama"],
+                                          o["pack_max_degen"], o["pack_min_gc"], o["pack_max_gc"],
+                                          o["min_primer"], o["optimize_5"], o["optimize_3"])
+
+    def add_target(self, seq, weight=1.0, active=True):
+        if self.f("session_add_target")(self.h, seq.encode(), weight, int(active)) != 0:
+            raise RuntimeError(self.f("session_error")(self.h))
+        self.n += 1
+
+    def add_target_packed(self, packed, length, weight=1.0, active=True):
+        assert isinstance(self.L, Oracle)
+        buf = np.ascontiguousarray(packed, dtype=np.uint8)
+        self.L.lib.orc_session_add_target_packed(self.h, buf.ctypes.data, int(length), weight, int(active))
+        self.n += 1
+
+    def set_active(self, idx, active):
+        assert self.f("session_set_active")(self.h, idx, int(active)) == 0
+
+    def split(self, idx, pos):
+        assert self.f("session_split")(self.h, idx, pos) == 0
+
+    def select(self, pairs, threshold=-1.0, min_len_override=-1):
+        a = pairs_array(pairs)
+        n = self.f("session_select")(self.h, a.ctypes.data, len(pairs), threshold, min_len_override)
+        if n < 0:
+            raise RuntimeError(self.f("session_error")(self.h))
+        return n
+
+    def db_entries(self):
+        cap = 1 << 16
+        while True:
+            buf = (Entry * cap)()
+            n = self.f("session_db_entries")(self.h, buf, cap)
+            if n <= cap:
+                break
+            cap = n
+        return sorted((e.w[0], e.w[1], e.loc, e.index, e.strand) for e in buf[:n])
+
+    def target_match(self, pair, orient=False):
+        a = pairs_array([pair])
+        bits = np.zeros(self.n, dtype=np.uint8)
+        if isinstance(self.L, Oracle):
+            ori = np.zeros(self.n, dtype=np.uint8)
+            rc = self.L.lib.orc_session_target_match(self.h, a.ctypes.data, bits.ctypes.data, ori.ctypes.data)
+            if rc != 0:
+                raise RuntimeError(self.f("session_error")(self.h))
+            return (bits, ori) if orient else bits
+        rc = self.L.lib.ref_session_target_match(self.h, a.ctypes.data, bits.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(self.f("session_error")(self.h))
+        return bits
+
+    def target_coverage(self, pair):
+        a = pairs_array([pair])
+        return self.f("session_target_coverage")(self.h, a.ctypes.data)
+
+    def weighted_coverage(self, bits):
+        assert isinstance(self.L, Oracle)
+        b = np.ascontiguousarray(bits, dtype=np.uint8)
+        return self.L.lib.orc_weighted_coverage(self.h, b.ctypes.data)

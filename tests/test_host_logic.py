@@ -1,0 +1,135 @@
+"""CPU tests of the product's host half (through the C-ABI's host-only helpers): the window
+model must reproduce Sequence::pack exactly -- irregular words UNION (valid regular windows,
+both strands) == the oracle's pack() output -- and the candidate list must match select_words'.
+"""
+import random
+
+import numpy as np
+import pytest
+
+from pcramp_amd import api, words as W
+from testdata import rand_seq, revcomp
+
+
+def window_entries(seq_txt, valid, index=0):
+    """What the GPU implies for regular windows: (word, loc, strand) for both strands."""
+    out = []
+    codes = W.codes_from_text(seq_txt)
+    for p in np.nonzero(valid)[0]:
+        win = codes[p:p + 32]
+        plus = W.word_from_slots(win)
+        minus = W.word_from_slots(W.revcomp_codes(win))
+        out.append((plus[0], plus[1], int(p), index, 1))          # sequence.cpp:184
+        out.append((minus[0], minus[1], int(p) + 31, index, 2))   # sequence.cpp:190
+    return out
+
+
+CASES = [
+    (23, 0.0, 0.0, [], 18, 256, 0.0, 1.0), (31, 0.0, 0.0, [], 18, 256, 0.0, 1.0),
+    (32, 0.0, 0.0, [], 18, 256, 0.0, 1.0), (33, 0.0, 0.0, [], 18, 256, 0.0, 1.0),
+    (34, 0.0, 0.0, [], 18, 256, 0.0, 1.0), (35, 0.0, 0.0, [], 18, 256, 0.0, 1.0),
+    (64, 0.0, 0.0, [], 18, 256, 0.0, 1.0), (65, 0.0, 0.0, [], 18, 256, 0.0, 1.0),
+    (77, 0.0, 0.0, [], 18, 256, 0.0, 1.0), (200, 0.05, 0.02, [], 18, 256, 0.0, 1.0),
+    (201, 0.05, 0.02, [], 16, 256, 0.0, 1.0), (300, 0.0, 0.0, [100], 18, 256, 0.0, 1.0),
+    (301, 0.0, 0.0, [100, 101, 102, 103], 18, 256, 0.0, 1.0), (300, 0.0, 0.0, [5, 150, 170, 299], 18, 256, 0.0, 1.0),
+    (300, 0.0, 0.0, [0, 1, 40], 16, 256, 0.0, 1.0), (257, 0.1, 0.05, [64, 65, 128], 18, 16, 0.0, 1.0),
+    (400, 0.0, 0.0, [], 18, 256, 0.3, 0.7), (401, 0.02, 0.0, [200], 18, 256, 0.4, 0.6),
+    (150, 0.0, 0.3, [], 18, 256, 0.0, 1.0), (90, 0.0, 0.0, [44, 45], 10, 256, 0.0, 1.0),
+    (1200, 0.01, 0.01, [31, 32, 63, 64, 95, 600, 633, 1199], 18, 256, 0.0, 1.0),
+    (1201, 0.0, 0.0, [1200], 18, 256, 0.0, 1.0), (500, 0.0, 0.0, [468], 18, 256, 0.0, 1.0),
+    (500, 0.0, 0.0, [467, 499], 18, 256, 0.0, 1.0), (3, 0.0, 0.0, [], 1, 256, 0.0, 1.0),
+]
+
+
+@pytest.mark.parametrize("ci", range(len(CASES)))
+def test_window_model_equals_pack(oracle, ci):
+    L, pd, pn, eos, min_len, degen_thr, min_gc, max_gc = CASES[ci]
+    rng = random.Random(500 + ci)
+    for rep in range(4):
+        s = list(rand_seq(rng, L, p_degen=pd, p_n=pn))
+        for e in eos:
+            s[e] = "-"
+        s = "".join(s)
+        packed = W.pack_codes(W.codes_from_text(s))
+        irr = api.host_irregular_words(packed, L, min_len, degen_thr, min_gc, max_gc)
+        valid = api.host_window_valid(packed, L, degen_thr, min_gc, max_gc)
+        got = sorted([(a, b, loc, 0, st) for (a, b, loc, st) in irr] + window_entries(s, valid))
+        want = oracle.pack(s, 0, degen_thr, min_gc, max_gc, min_len)
+        assert got == want
+
+
+def test_irregular_count_is_small():
+    rng = random.Random(9)
+    s = rand_seq(rng, 5000)
+    packed = W.pack_codes(W.codes_from_text(s))
+    irr = api.host_irregular_words(packed, len(s), 18)
+    assert len(irr) < 80   # head + tail partial words only
+
+
+@pytest.mark.parametrize("opt5,opt3", [(0, 0), (1, 0), (0, 1), (1, 1)])
+def test_candidates_match_oracle_shifts(oracle, opt5, opt3):
+    rng = random.Random(3)
+    pairs = []
+    for _ in range(10):
+        f = oracle.centered_word(rand_seq(rng, rng.randint(18, 25), p_degen=0.1))
+        r = oracle.centered_word(rand_seq(rng, rng.randint(18, 25)))
+        pairs.append((f, r))
+    thr = 0.9
+    words, floors = api.host_candidates(pairs, opt5, opt3, thr)
+    want = []
+    for f, r in pairs:
+        for o in (f, r):
+            want.append(o)
+            cs, ce = oracle.word_start(o), oracle.word_stop(o)
+            if opt5 and cs > 0:
+                t = o
+                for _ in range(cs):
+                    t = oracle.word_shift_left(t)
+                    want.append(t)
+            if opt3 and ce < 31:
+                t = o
+                for _ in range(ce, 31):
+                    t = oracle.word_shift_right(t)
+                    want.append(t)
+    assert words == want
+    for w, fl in zip(words, floors):
+        assert int(fl) == int(np.float32(oracle.word_size(w)) * np.float32(thr))
+
+
+def test_centered_word_matches_oracle(oracle):
+    rng = random.Random(4)
+    for n in range(1, 33):
+        s = rand_seq(rng, n, p_degen=0.2)
+        assert W.centered_word(W.codes_from_text(s)) == oracle.centered_word(s)
+        assert W.word_text(oracle.centered_word(s)) == s
+
+
+def test_coverage_from_bits_order():
+    # compute_coverage visits {F(+),R(-)} amplicons first, then {R(+),F(-)}: the double sum
+    # must follow that order, not plain ascending index.
+    w = np.array([1e8, 1.0, 1e-8, 3.0], np.float32)
+    fr = np.array([0b1000], np.uint64)
+    rf = np.array([0b0111], np.uint64)
+    exp = np.float32(np.float64(w[3]) + np.float64(w[0]) + np.float64(w[1]) + np.float64(w[2]))
+    assert api.coverage_from_bits(fr, rf, w) == exp
+    assert api.weighted_coverage(np.array([0b1111], np.uint64), w) == np.float32(
+        np.float64(w[0]) + np.float64(w[1]) + np.float64(w[2]) + np.float64(w[3]))
+
+
+def test_abi_exports_every_declared_symbol():
+    import re, os
+    L = api.load_library()
+    hdr = open(os.path.join(os.path.dirname(api.library_path()), "..", "include", "pcramp_hip.h")).read()
+    declared = set(re.findall(r"\b(pcr_[a-z_0-9]+)\s*\(", hdr))
+    declared -= {"pcr_ctx"}
+    assert declared == set(api.ABI_SYMBOLS)
+    for name in declared:
+        assert hasattr(L, name), name
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(api.PcrError):
+        api.Screener(0)

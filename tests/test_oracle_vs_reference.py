@@ -1,0 +1,160 @@
+"""Pins the CPU restatement (oracle/pcr_oracle.cpp) against the REAL reference, compiled from
+/root/reference by oracle/Makefile behind oracle/ref_harness.cpp.  Runs only where that build
+exists (this container); the committed goldens in tests/golden/ carry the same pins to the GPU box.
+"""
+import random
+
+import numpy as np
+import pytest
+
+from testdata import rand_seq, family_targets, sample_pair, mutate
+
+pytestmark = pytest.mark.usefixtures("reference")
+
+
+def rand_word(rng, lib, lo=1, hi=32, p_degen=0.2):
+    n = rng.randint(lo, hi)
+    return lib.word(rand_seq(rng, n, p_degen=p_degen))
+
+
+def test_word_primitives(oracle, reference):
+    rng = random.Random(1)
+    for it in range(3000):
+        s = rand_seq(rng, rng.randint(1, 32), p_degen=0.3)
+        a_o, a_r = oracle.word(s), reference.word(s)
+        assert a_o == a_r
+        # push the word around so that it sits at arbitrary slots
+        for _ in range(rng.randint(0, 8)):
+            if rng.random() < 0.5:
+                a_o, a_r = oracle.word_shift_right(a_o), reference.word_shift_right(a_r)
+            else:
+                a_o, a_r = oracle.word_shift_left(a_o), reference.word_shift_left(a_r)
+        assert a_o == a_r
+        b = reference.word(rand_seq(rng, rng.randint(1, 32), p_degen=0.3))
+        assert oracle.word_and(a_o, b) == reference.word_and(a_r, b)
+        assert oracle.word_size(a_o) == reference.word_size(a_r)
+        assert oracle.word_start(a_o) == reference.word_start(a_r)
+        assert oracle.word_stop(a_o) == reference.word_stop(a_r)
+        assert oracle.word_degeneracy(a_o) == reference.word_degeneracy(a_r)
+        if oracle.word_size(a_o) > 0:
+            assert oracle.word_center(a_o) == reference.word_center(a_r)
+            assert oracle.word_complement(a_o) == reference.word_complement(a_r)
+
+
+def test_word_expansion_order(oracle, reference):
+    rng = random.Random(2)
+    for it in range(300):
+        s = rand_seq(rng, rng.randint(4, 25), p_degen=0.15)
+        w = reference.centered_word(s)
+        if reference.word_degeneracy(w) > 512:
+            continue
+        assert oracle.word_expand(w) == reference.word_expand(w)
+
+
+def test_taq_mama_table(oracle, reference):
+    for p1 in range(16):
+        for p2 in range(16):
+            for t1 in range(16):
+                for t2 in range(16):
+                    assert oracle.taq_mama(p1, p2, t1, t2) == reference.taq_mama(p1, p2, t1, t2)
+
+
+PACK_CASES = [
+    # (length, p_degen, p_n, eos positions, min_len, degen_thr, min_gc, max_gc)
+    (23, 0.0, 0.0, [], 18, 256, 0.0, 1.0),
+    (31, 0.0, 0.0, [], 18, 256, 0.0, 1.0),
+    (32, 0.0, 0.0, [], 18, 256, 0.0, 1.0),
+    (33, 0.0, 0.0, [], 18, 256, 0.0, 1.0),
+    (34, 0.0, 0.0, [], 18, 256, 0.0, 1.0),
+    (35, 0.0, 0.0, [], 18, 256, 0.0, 1.0),
+    (77, 0.0, 0.0, [], 18, 256, 0.0, 1.0),
+    (200, 0.05, 0.02, [], 18, 256, 0.0, 1.0),
+    (201, 0.05, 0.02, [], 16, 256, 0.0, 1.0),
+    (300, 0.0, 0.0, [100], 18, 256, 0.0, 1.0),
+    (301, 0.0, 0.0, [100, 101, 102, 103], 18, 256, 0.0, 1.0),
+    (300, 0.0, 0.0, [5, 150, 170, 299], 18, 256, 0.0, 1.0),
+    (300, 0.0, 0.0, [0, 1, 40], 16, 256, 0.0, 1.0),
+    (257, 0.1, 0.05, [64, 65, 128], 18, 16, 0.0, 1.0),
+    (400, 0.0, 0.0, [], 18, 256, 0.3, 0.7),
+    (401, 0.02, 0.0, [200], 18, 256, 0.4, 0.6),
+    (150, 0.0, 0.3, [], 18, 256, 0.0, 1.0),
+    (90, 0.0, 0.0, [44, 45], 10, 256, 0.0, 1.0),
+]
+
+
+@pytest.mark.parametrize("ci", range(len(PACK_CASES)))
+def test_pack(oracle, reference, ci):
+    L, pd, pn, eos, min_len, degen_thr, min_gc, max_gc = PACK_CASES[ci]
+    rng = random.Random(1000 + ci)
+    for rep in range(3):
+        s = list(rand_seq(rng, L, p_degen=pd, p_n=pn))
+        for e in eos:
+            s[e] = "-"
+        s = "".join(s)
+        a = oracle.pack(s, 7, degen_thr, min_gc, max_gc, min_len)
+        b = reference.pack(s, 7, degen_thr, min_gc, max_gc, min_len)
+        assert a == b
+
+
+def _sessions(oracle, reference, seqs, weights=None, **opts):
+    so, sr = oracle.session(**opts), reference.session(**opts)
+    for i, s in enumerate(seqs):
+        w = 1.0 if weights is None else weights[i]
+        so.add_target(s, w)
+        sr.add_target(s, w)
+    return so, sr
+
+
+SELECT_CASES = [
+    dict(),
+    dict(target_threshold=0.9, search_multiplier=0.9),
+    dict(target_threshold=0.8, search_multiplier=0.9, use_taq_mama=1),
+    dict(target_threshold=0.9, optimize_5=1, optimize_3=1),
+    dict(target_threshold=0.85, amp_min=60, amp_max=300, use_taq_mama=1),
+]
+
+
+@pytest.mark.parametrize("opts", SELECT_CASES)
+def test_select_and_amplify(oracle, reference, opts):
+    rng = random.Random(11 + len(opts))
+    seqs = family_targets(rng, 3, 6, 700, div=0.04)
+    # a few ragged ones: short, with N runs, with EOS splits
+    seqs.append(rand_seq(rng, 40))
+    seqs.append(rand_seq(rng, 333, p_degen=0.03, p_n=0.02))
+    s = list(seqs[0]); s[350] = "-"; seqs.append("".join(s))
+    weights = [1.0 + 0.37 * (i % 5) for i in range(len(seqs))]
+    pairs_txt = []
+    while len(pairs_txt) < 12:
+        p = sample_pair(rng, rng.choice(seqs[:18]))
+        if p:
+            pairs_txt.append(p)
+    # primers that sit at the very ends of a sequence (partial-word territory)
+    s0 = seqs[1]
+    pairs_txt.append((s0[0:20], __import__("testdata").revcomp(s0[100:120])))
+    pairs_txt.append((s0[len(s0) - 150:len(s0) - 130], __import__("testdata").revcomp(s0[len(s0) - 21:])))
+    pairs = [(reference.centered_word(f), reference.centered_word(r)) for f, r in pairs_txt]
+    so, sr = _sessions(oracle, reference, seqs, weights, **opts)
+    assert so.select(pairs) == sr.select(pairs)
+    assert so.db_entries() == sr.db_entries()
+    for p in pairs:
+        assert (so.target_match(p) == sr.target_match(p)).all()
+        assert so.target_coverage(p) == sr.target_coverage(p)
+
+
+def test_inactive_and_split(oracle, reference):
+    rng = random.Random(5)
+    seqs = family_targets(rng, 2, 5, 600, div=0.03)
+    pairs_txt = [sample_pair(rng, seqs[i % len(seqs)]) for i in range(8)]
+    pairs = [(reference.centered_word(f), reference.centered_word(r)) for f, r in pairs_txt]
+    so, sr = _sessions(oracle, reference, seqs, target_threshold=0.9)
+    for s in (so, sr):
+        s.set_active(2, False)
+        s.set_active(7, False)
+        s.split(0, 300)
+        s.split(4, 10)
+        s.split(4, 580)
+    assert so.select(pairs) == sr.select(pairs)
+    assert so.db_entries() == sr.db_entries()
+    for p in pairs:
+        assert (so.target_match(p) == sr.target_match(p)).all()
+        assert so.target_coverage(p) == sr.target_coverage(p)
