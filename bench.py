@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py -- primer-pair x target amplification evaluations / second on MI355X.
+
+One step = one pass of the hot path over one batch of synthetic input, inputs already resident
+in HBM: the per-iteration index build (Sequence::pack + select_words for every target,
+reference main.cpp:644-691) followed by the amplicon screen of every primer pair against every
+target (PCR::find_target_match, pcr_assay.cpp:544).  Workload at N=1: BASELINE.json configs[1]
+("C2": 10 000 viral targets x 10 kb, 50 primer pairs).  With --gpus N each rank owns its own
+10 000-target shard (weak scaling; targets shard with no data-path collective except the one
+all-gather of the per-target coverage bitsets per pass).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def cpu_baseline(wl, thr_t, mult, budget_s=15.0):
+    """Time the CPU path on a bounded sample of the SAME workload (rank 0, N=1 only).
+    Prefers the real reference (oracle/_ref, kind "reference"), else our restatement ("port")."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    cores = min(16, len(os.sched_getaffinity(0)))
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    from oracle_lib import Oracle, Reference
+    from pcramp_amd import words as W
+    kind = "reference" if Reference.available() else "port"
+    lib = Reference() if kind == "reference" else Oracle()
+    if kind == "port":
+        cores = 1
+    nb = (wl["L"] + 1) // 2
+
+    def run(n_t):
+        s = lib.session(target_threshold=thr_t, search_multiplier=mult)
+        for i in range(n_t):
+            o = int(wl["byte_offsets"][i])
+            codes = W.unpack_codes(wl["packed"][o:o + nb], wl["L"])
+            s.add_target(W.text_from_codes(codes))
+        t0 = time.perf_counter()
+        s.select(wl["pairs"])
+        for p in wl["pairs"]:
+            s.target_match(p)
+        return time.perf_counter() - t0
+
+    n_t = min(4, wl["T"])
+    dt = run(n_t)
+    per_target = dt / n_t
+    n_big = int(max(n_t, min(wl["T"], budget_s / max(per_target, 1e-9))))
+    if n_big > n_t:
+        dt = run(n_big)
+        n_t = n_big
+    evals = n_t * len(wl["pairs"])
+    return {"value": evals / dt, "unit": "evals/s", "cores": cores, "kind": kind,
+            "sample": "%d of the %d targets (%d bases each) x %d pairs: select_words + find_target_match, %.1f s"
+                      % (n_t, wl["T"], wl["L"], len(wl["pairs"]), dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="C2")
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink the target count (debug only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from pcramp_amd import api, synth, words as W
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev_t = torch.device("cuda", local_rank)
+
+    thr_t, mult = 0.9, 0.9
+    select_thr = float(np.float32(thr_t) * np.float32(mult))
+
+    # every rank owns a different shard of the same family structure; the primer pairs are
+    # replicated (rank 0's), as the reference broadcasts its trial assays
+    wl = synth.workload(args.config, seed_offset=rank, scale=args.scale)
+    pairs = wl["pairs"]
+    if world > 1:
+        obj = [pairs if rank == 0 else None]
+        dist.broadcast_object_list(obj, src=0)
+        pairs = obj[0]
+        wl["pairs"] = pairs
+    pa = W.pairs_array(pairs)
+    T, L, P = wl["T"], wl["L"], len(pairs)
+
+    stream = torch.cuda.current_stream().cuda_stream
+    scr = api.Screener(local_rank, stream=stream)
+    scr.load_sequences(wl["packed"], wl["byte_offsets"], wl["lengths"])
+    words = int(scr.bitset_words())
+    local = torch.zeros((2, P, words), dtype=torch.int64, device=dev_t)
+    gathered = torch.zeros((world, 2, P, words), dtype=torch.int64, device=dev_t) if world > 1 else None
+
+    def step():
+        scr.select_words(pa, select_thr, 18)
+        scr.amplify_device(pa, local[0].data_ptr(), local[1].data_ptr(), thr_t, thr_t, 80, 200, False)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, local)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    scr.profile(True)
+    scr.profile_read(reset=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    scan_ms, scan_launches = scr.profile_read(reset=True)
+    scr.profile(False)
+
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev_t)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    n_set = int(sum(bin(int(x) & 0xFFFFFFFFFFFFFFFF).count("1") for x in (local[0] | local[1]).flatten().tolist()))
+    evals_total = float(P) * T * world * args.steps
+    value = evals_total / dt
+
+    if rank == 0:
+        # dominant kernel: the oligo x window match scan.  Algorithmic bytes per evaluation
+        # (SURVEY.md section 8d): ceil(L/2) packed target bytes + 2 x 16-byte oligos + 1 result bit.
+        b_eval = (L + 1) // 2 + 32 + 0.125
+        evals_per_launch = float(P) * T
+        kern_s = (scan_ms / 1e3) / max(scan_launches, 1)
+        achieved = evals_per_launch * b_eval / kern_s / 1e9 if kern_s > 0 else 0.0
+        out = {
+            "metric": "primer-pair x target amplification evals/sec",
+            "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "%s: %d targets x %d bases per GPU, %d primer pairs (18-25 nt), "
+                                   "select_words thr %.2f + find_target_match thr %.2f, amplicon 80-200"
+                                   % (args.config, T, L, P, select_thr, thr_t),
+                       "targets_per_gpu": T, "target_len": L, "pairs": P, "sharding": "targets x%d" % world,
+                       "amplification_calls_set_rank0": n_set},
+            "roofline": {"bound": "hbm", "kernel": "k_scan", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel_ms": kern_s * 1e3, "launches": int(scan_launches),
+                         "algorithmic_bytes_per_launch": evals_per_launch * b_eval},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            scr.close()
+            out["cpu_baseline"] = cpu_baseline(wl, thr_t, mult, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
