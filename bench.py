@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--config", default="C2")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the target count (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--random-primers", action="store_true", help="diagnostic: primers unrelated to the targets (no hits)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -97,6 +98,11 @@ def main():
     # replicated (rank 0's), as the reference broadcasts its trial assays
     wl = synth.workload(args.config, seed_offset=rank, scale=args.scale)
     pairs = wl["pairs"]
+    if args.random_primers:
+        rs = np.random.RandomState(7)
+        pairs = [(W.centered_word(2 ** rs.randint(0, 4, size=rs.randint(18, 26))),
+                  W.centered_word(2 ** rs.randint(0, 4, size=rs.randint(18, 26)))) for _ in range(len(pairs))]
+        wl["pairs"] = pairs
     if world > 1:
         obj = [pairs if rank == 0 else None]
         dist.broadcast_object_list(obj, src=0)

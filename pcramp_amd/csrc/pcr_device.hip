@@ -5,6 +5,8 @@
 //               (the reference's 4-bit IUPAC nibble, bit-transposed: same 4 bits/base as
 //               Sequence::seq_buffer, sequence.h:86).  EOS / past-the-end = no bit in any plane.
 //               Each sequence owns ceil(L/32)+2 blocks (two zero halo blocks).
+//   nib[]     : the same codes as 4 u32 per block, nibble j%8 of word j/8 = base 32*b+j (table index of
+//               the bit-sliced scan, pcr_scan_bitsliced.inc).
 //   valid[]   : one u32 per block; bit j = the 32-base window starting at 32*b+j is a REGULAR
 //               window that Sequence::pack emits (sequence.cpp:127-153 filters applied).
 //   irr[]     : explicit irregular words (pcr_host.hpp).
@@ -21,6 +23,7 @@
 #include <stdint.h>
 #include <string.h>
 #include <math.h>
+#include <stdlib.h>
 #include <string>
 #include <vector>
 #include <algorithm>
@@ -99,7 +102,7 @@ __device__ __forceinline__ uint32_t match_count(uint32_t wa, uint32_t wc, uint32
 // One thread per 32-base block: nibbles (high first, sequence.h:223-228) -> four bit planes.
 __global__ void k_transpose(const uint8_t *__restrict__ packed, const uint64_t *__restrict__ byte_off,
 	const uint64_t *__restrict__ len, const uint64_t *__restrict__ blk_off, const uint32_t *__restrict__ blk_seq,
-	uint4 *__restrict__ planes, uint64_t total_blocks)
+	uint4 *__restrict__ planes, uint32_t *__restrict__ nib, uint64_t total_blocks)
 {
 	const uint64_t gb = (uint64_t)blockIdx.x*blockDim.x + threadIdx.x;
 	if(gb >= total_blocks) return;
@@ -108,17 +111,20 @@ __global__ void k_transpose(const uint8_t *__restrict__ packed, const uint64_t *
 	const uint64_t L = len[s];
 	const uint8_t *src = packed + byte_off[s];
 	uint32_t a = 0, c = 0, g = 0, t = 0;
+	uint32_t nw[4] = {0, 0, 0, 0};   // the same 32 codes, nibble j%8 of word j/8 (v2 scan's table index)
 	for(int j = 0;j < 32;++j){
 		const uint64_t pos = b*32 + j;
 		if(pos >= L) break;
 		const uint8_t v = src[pos >> 1];
-		const uint32_t nib = (pos & 1) ? (v & 0xF) : (v >> 4);
-		a |= (nib & 1u) << j;
-		c |= ((nib >> 1) & 1u) << j;
-		g |= ((nib >> 2) & 1u) << j;
-		t |= ((nib >> 3) & 1u) << j;
+		const uint32_t code = (pos & 1) ? (v & 0xF) : (v >> 4);
+		a |= (code & 1u) << j;
+		c |= ((code >> 1) & 1u) << j;
+		g |= ((code >> 2) & 1u) << j;
+		t |= ((code >> 3) & 1u) << j;
+		nw[j >> 3] |= code << ((j & 7)*4);
 	}
 	planes[gb] = make_uint4(a, c, g, t);
+	((uint4 *)nib)[gb] = make_uint4(nw[0], nw[1], nw[2], nw[3]);
 }
 
 // One thread per block: validity of the 32 windows that START in it.  A window is regular iff
@@ -266,6 +272,8 @@ __global__ void k_scan_irr(const IrrDev *__restrict__ irr, uint32_t n_irr, const
 		if(cnt >= cand_floor[c]) record_hit(best, hits, counters, hit_cap, ncand, e.seq, c, key, cnt);
 	}
 }
+
+#include "pcr_scan_bitsliced.inc"
 
 // Keep the hits that attain the final per-(sequence,candidate) maximum (select_words.cpp:100-117).
 __global__ void k_filter(const Hit *__restrict__ hits, uint32_t n_hits, const uint32_t *__restrict__ best,
@@ -466,7 +474,7 @@ struct SeqSet {
 	uint64_t total_blocks = 0;
 	uint32_t n_tiles = 0, n_irr = 0;
 	DevBuf<uint4> planes;
-	DevBuf<uint32_t> valid, blk_seq, tile_seq, tile_pos0, irr_off, seg_lo, seg_hi;
+	DevBuf<uint32_t> valid, nib, blk_seq, tile_seq, tile_pos0, irr_off, seg_lo, seg_hi;
 	DevBuf<uint64_t> d_len, d_blk_off, d_nblk_real;
 	DevBuf<uint8_t> d_active;
 	DevBuf<IrrDev> irr;
@@ -476,7 +484,7 @@ struct SeqSet {
 	DevBuf<DevEntry> db;
 	void release()
 	{
-		planes.release(); valid.release(); blk_seq.release(); tile_seq.release(); tile_pos0.release();
+		planes.release(); valid.release(); nib.release(); blk_seq.release(); tile_seq.release(); tile_pos0.release();
 		irr_off.release(); seg_lo.release(); seg_hi.release(); d_len.release(); d_blk_off.release();
 		d_nblk_real.release(); d_active.release(); irr.release(); db.release();
 	}
@@ -493,7 +501,8 @@ struct pcr_ctx {
 	SeqSet sets[2];
 	// scratch
 	DevBuf<uint4> cand_fwd, cand_rc;
-	DevBuf<uint32_t> cand_floor, best, counters, mask, status;
+	DevBuf<uint32_t> cand_floor, best, counters, mask, status, tab, bias;
+	int scan_version = 2;
 	DevBuf<Hit> hits;
 	DevBuf<uint64_t> keys, keys_sorted, keys_unique, bits_fr, bits_rf;
 	DevBuf<uint8_t> cub_tmp;
@@ -591,6 +600,45 @@ int amplify_launch(pcr_ctx *ctx, SeqSet &S, const pcr_pair *pairs, uint32_t n_pa
 	return PCR_OK;
 }
 
+template<int NSLOT, int KLO>
+int launch_scan2_nw(pcr_ctx *ctx, SeqSet &S, uint32_t nw, uint32_t group0, uint32_t n_groups, uint32_t ncand)
+{
+#define SCAN2_ARGS S.nib.p, S.planes.p, S.valid.p, S.d_blk_off.p, S.d_len.p, S.d_active.p, S.tile_seq.p, S.tile_pos0.p, \
+	ctx->tab.p, ctx->bias.p, group0, ctx->cand_fwd.p, ctx->cand_rc.p, ctx->cand_floor.p, ncand, ctx->best.p, ctx->hits.p, \
+	ctx->counters.p, (uint32_t)ctx->hit_cap
+	const dim3 grid(S.n_tiles, n_groups), block(SCAN2_THREADS);
+	switch(nw){
+		case 1: hipLaunchKernelGGL((k_scan2<1, NSLOT, KLO>), grid, block, 0, ctx->stream, SCAN2_ARGS); break;
+		case 2: hipLaunchKernelGGL((k_scan2<2, NSLOT, KLO>), grid, block, 0, ctx->stream, SCAN2_ARGS); break;
+		case 3: hipLaunchKernelGGL((k_scan2<3, NSLOT, KLO>), grid, block, 0, ctx->stream, SCAN2_ARGS); break;
+		case 4: hipLaunchKernelGGL((k_scan2<4, NSLOT, KLO>), grid, block, 0, ctx->stream, SCAN2_ARGS); break;
+		case 5: hipLaunchKernelGGL((k_scan2<5, NSLOT, KLO>), grid, block, 0, ctx->stream, SCAN2_ARGS); break;
+		case 6: hipLaunchKernelGGL((k_scan2<6, NSLOT, KLO>), grid, block, 0, ctx->stream, SCAN2_ARGS); break;
+		case 7: hipLaunchKernelGGL((k_scan2<7, NSLOT, KLO>), grid, block, 0, ctx->stream, SCAN2_ARGS); break;
+		default: hipLaunchKernelGGL((k_scan2<8, NSLOT, KLO>), grid, block, 0, ctx->stream, SCAN2_ARGS); break;
+	}
+#undef SCAN2_ARGS
+	HIP_TRY(hipGetLastError());
+	return PCR_OK;
+}
+
+// The bit-sliced scan over all orientation groups: full groups (8 words) in one launch, the
+// partial last group in a second one.
+int launch_scan2(pcr_ctx *ctx, SeqSet &S, const Scan2Tables &T, uint32_t ncand)
+{
+	const uint32_t full = (T.last_words == 8) ? T.n_groups : T.n_groups - 1;
+	int rc = PCR_OK;
+	if(full){
+		rc = (T.nslot == 26) ? launch_scan2_nw<26, 3>(ctx, S, 8, 0, full, ncand) : launch_scan2_nw<32, 0>(ctx, S, 8, 0, full, ncand);
+		if(rc != PCR_OK) return rc;
+	}
+	if(full < T.n_groups){
+		rc = (T.nslot == 26) ? launch_scan2_nw<26, 3>(ctx, S, T.last_words, full, 1, ncand)
+			: launch_scan2_nw<32, 0>(ctx, S, T.last_words, full, 1, ncand);
+	}
+	return rc;
+}
+
 } // namespace
 
 // ============================================================================== C-ABI
@@ -622,6 +670,7 @@ pcr_ctx *pcr_create(int device, void *hip_stream, const pcr_params *params)
 	}
 	if(params){ ctx->params = *params; }
 	else{ ctx->params.pack_max_degen = 256; ctx->params.pack_min_gc = 0.0f; ctx->params.pack_max_gc = 1.0f; }
+	if(const char *v = getenv("PCRAMP_SCAN")){ if(v[0] == '1') ctx->scan_version = 1; }   // A/B: the v1 (per-orientation popcount) scan
 	ctx->filt.max_degen = ctx->params.pack_max_degen;
 	ctx->filt.set_gc(ctx->params.pack_min_gc, ctx->params.pack_max_gc);
 	if(hipMemcpyToSymbol(HIP_SYMBOL(c_taq_mama), h_taq_mama, sizeof(h_taq_mama)) != hipSuccess){
@@ -640,7 +689,7 @@ void pcr_destroy(pcr_ctx *ctx)
 	ctx->cand_fwd.release(); ctx->cand_rc.release(); ctx->cand_floor.release(); ctx->best.release();
 	ctx->counters.release(); ctx->mask.release(); ctx->status.release(); ctx->hits.release(); ctx->keys.release();
 	ctx->keys_sorted.release(); ctx->keys_unique.release(); ctx->bits_fr.release(); ctx->bits_rf.release();
-	ctx->cub_tmp.release(); ctx->n_unique.release(); ctx->oligos.release();
+	ctx->cub_tmp.release(); ctx->n_unique.release(); ctx->oligos.release(); ctx->tab.release(); ctx->bias.release();
 	if(ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
@@ -715,6 +764,7 @@ int pcr_load_sequences(pcr_ctx *ctx, pcr_set which, const uint8_t *packed4, cons
 	auto fail = [&](int code){ d_packed.release(); d_byte_off.release(); return code; };
 	if((rc = S.planes.ensure(total_blocks)) != PCR_OK) return fail(rc);
 	if((rc = S.valid.ensure(total_blocks)) != PCR_OK) return fail(rc);
+	if((rc = S.nib.ensure(total_blocks*4 + 8)) != PCR_OK) return fail(rc);
 	if((rc = S.blk_seq.ensure(total_blocks)) != PCR_OK) return fail(rc);
 	if((rc = S.tile_seq.ensure(n_tiles)) != PCR_OK) return fail(rc);
 	if((rc = S.tile_pos0.ensure(n_tiles)) != PCR_OK) return fail(rc);
@@ -740,7 +790,7 @@ int pcr_load_sequences(pcr_ctx *ctx, pcr_set which, const uint8_t *packed4, cons
 		const unsigned threads = 256;
 		const unsigned grid = (unsigned)((total_blocks + threads - 1)/threads);
 		hipLaunchKernelGGL(k_transpose, dim3(grid), dim3(threads), 0, ctx->stream, d_packed.p, d_byte_off.p, S.d_len.p,
-			S.d_blk_off.p, S.blk_seq.p, S.planes.p, total_blocks);
+			S.d_blk_off.p, S.blk_seq.p, S.planes.p, S.nib.p, total_blocks);
 		if(hipGetLastError() != hipSuccess){ g_err = "k_transpose launch failed"; return fail(PCR_ERR_DEVICE); }
 		if((rc = run_valid(ctx, S, 0, total_blocks)) != PCR_OK) return fail(rc);
 	}
@@ -775,6 +825,13 @@ int pcr_split(pcr_ctx *ctx, pcr_set which, uint32_t seq, uint64_t pos)
 	const uint32_t m = ~(1u << (pos & 31));
 	blk.x &= m; blk.y &= m; blk.z &= m; blk.w &= m;
 	HIP_TRY(hipMemcpy(S.planes.p + gb, &blk, sizeof(uint4), hipMemcpyHostToDevice));
+	{
+		uint32_t nword;
+		uint32_t *np = S.nib.p + gb*4 + ((pos & 31) >> 3);
+		HIP_TRY(hipMemcpy(&nword, np, sizeof(uint32_t), hipMemcpyDeviceToHost));
+		nword &= ~(0xFu << ((pos & 7)*4));
+		HIP_TRY(hipMemcpy(np, &nword, sizeof(uint32_t), hipMemcpyHostToDevice));
+	}
 	const uint64_t first = (gb > S.blk_off[seq]) ? gb - 1 : gb;
 	int rc = run_valid(ctx, S, first, gb - first + 1);
 	if(rc != PCR_OK) return rc;
@@ -814,6 +871,15 @@ int pcr_select_words(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_
 	HIP_TRY(hipMemcpyAsync(ctx->cand_rc.p, hr.data(), ncand*sizeof(uint4), hipMemcpyHostToDevice, ctx->stream));
 	HIP_TRY(hipMemcpyAsync(ctx->cand_floor.p, hfl.data(), ncand*sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
 
+	Scan2Tables tables;
+	if(ctx->scan_version != 1){
+		build_scan2_tables(cand, tables);
+		if((rc = ctx->tab.ensure(tables.tab.size())) != PCR_OK) return rc;
+		if((rc = ctx->bias.ensure(tables.bias.size())) != PCR_OK) return rc;
+		HIP_TRY(hipMemcpyAsync(ctx->tab.p, tables.tab.data(), tables.tab.size()*sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+		HIP_TRY(hipMemcpyAsync(ctx->bias.p, tables.bias.data(), tables.bias.size()*sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+	}
+
 	uint32_t h_counters[4];
 	for(int attempt = 0;;++attempt){
 		if((rc = ctx->hits.ensure(ctx->hit_cap)) != PCR_OK) return rc;
@@ -826,10 +892,15 @@ int pcr_select_words(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_
 				HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
 				HIP_TRY(hipEventRecord(e0, ctx->stream));
 			}
-			hipLaunchKernelGGL(k_scan, dim3(S.n_tiles), dim3(SCAN_THREADS), 0, ctx->stream, S.planes.p, S.valid.p,
-				S.d_blk_off.p, S.d_len.p, S.d_active.p, S.tile_seq.p, S.tile_pos0.p, ctx->cand_fwd.p, ctx->cand_rc.p,
-				ctx->cand_floor.p, ncand, ctx->best.p, ctx->hits.p, ctx->counters.p, (uint32_t)ctx->hit_cap);
-			HIP_TRY(hipGetLastError());
+			if(ctx->scan_version == 1){
+				hipLaunchKernelGGL(k_scan, dim3(S.n_tiles), dim3(SCAN_THREADS), 0, ctx->stream, S.planes.p, S.valid.p,
+					S.d_blk_off.p, S.d_len.p, S.d_active.p, S.tile_seq.p, S.tile_pos0.p, ctx->cand_fwd.p, ctx->cand_rc.p,
+					ctx->cand_floor.p, ncand, ctx->best.p, ctx->hits.p, ctx->counters.p, (uint32_t)ctx->hit_cap);
+				HIP_TRY(hipGetLastError());
+			}
+			else{
+				if((rc = launch_scan2(ctx, S, tables, ncand)) != PCR_OK) return rc;
+			}
 			if(ctx->prof){
 				HIP_TRY(hipEventRecord(e1, ctx->stream));
 				ctx->prof_events.push_back(std::make_pair(e0, e1));
