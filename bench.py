@@ -122,7 +122,7 @@ def main():
         scr.select_words(pa, select_thr, 18)
         scr.amplify_device(pa, local[0].data_ptr(), local[1].data_ptr(), thr_t, thr_t, 80, 200, False)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, local)
+            dist.all_gather_into_tensor(gathered.view(-1), local.view(-1))
 
     for _ in range(args.warmup):
         step()
@@ -159,6 +159,12 @@ def main():
         evals_per_launch = float(P) * T
         kern_s = (scan_ms / 1e3) / max(scan_launches, 1)
         achieved = evals_per_launch * b_eval / kern_s / 1e9 if kern_s > 0 else 0.0
+        traffic = None
+        try:   # HBM bytes per launch of the scan kernel from the committed PMC passes (profiles/summarize.py)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
+            traffic = [v for k, v in tj.items() if k.startswith("k_scan2")][0] if args.config == "C2" and args.scale == 1.0 else None
+        except Exception:
+            traffic = None
         out = {
             "metric": "primer-pair x target amplification evals/sec",
             "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -169,8 +175,8 @@ def main():
                                    % (args.config, T, L, P, select_thr, thr_t),
                        "targets_per_gpu": T, "target_len": L, "pairs": P, "sharding": "targets x%d" % world,
                        "amplification_calls_set_rank0": n_set},
-            "roofline": {"bound": "hbm", "kernel": "k_scan", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": "k_scan2 (bit-sliced oligo x window match scan)", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel_ms": kern_s * 1e3, "launches": int(scan_launches),
                          "algorithmic_bytes_per_launch": evals_per_launch * b_eval},
         }

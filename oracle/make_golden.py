@@ -1,0 +1,127 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.json from the REAL reference (oracle/_ref/libpcramp_ref.so, built
+from /root/reference by oracle/Makefile).  Inputs are seeded random data made here; outputs are
+what the reference computes for them.  Only inputs + outputs are stored -- no reference source.
+
+    python oracle/make_golden.py          # rewrites tests/golden/
+
+The fixtures travel to the GPU box (which has no /root/reference) and pin both the CPU oracle
+(tests/test_oracle_golden.py) and the HIP path (tests/test_gpu_golden.py).
+"""
+import json
+import os
+import random
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
+
+from oracle_lib import Reference, build_reference  # noqa: E402
+from testdata import rand_seq, family_targets, sample_pair, revcomp  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def hexw(w):
+    return ["%016x" % w[0], "%016x" % w[1]]
+
+
+def words_golden(ref):
+    rng = random.Random(101)
+    cases = []
+    for _ in range(400):
+        a = ref.word(rand_seq(rng, rng.randint(1, 32), p_degen=0.3))
+        for _ in range(rng.randint(0, 8)):
+            a = ref.word_shift_right(a) if rng.random() < 0.5 else ref.word_shift_left(a)
+        b = ref.word(rand_seq(rng, rng.randint(1, 32), p_degen=0.3))
+        for _ in range(rng.randint(0, 6)):
+            b = ref.word_shift_right(b)
+        c = {"a": hexw(a), "b": hexw(b), "and": ref.word_and(a, b), "size": ref.word_size(a),
+             "start": ref.word_start(a), "stop": ref.word_stop(a), "degeneracy": ref.word_degeneracy(a)}
+        if ref.word_size(a) > 0:
+            c["center"] = hexw(ref.word_center(a))
+            c["complement"] = hexw(ref.word_complement(a))
+        cases.append(c)
+    exp = []
+    for _ in range(40):
+        w = ref.centered_word(rand_seq(rng, rng.randint(6, 25), p_degen=0.15))
+        if ref.word_degeneracy(w) <= 64:
+            exp.append({"word": hexw(w), "expansion": [hexw(x) for x in ref.word_expand(w)]})
+    taq = [[p1, p2, t1, t2, ref.taq_mama(p1, p2, t1, t2)] for p1 in (1, 2, 4, 8, 15) for p2 in (1, 2, 4, 8, 3)
+           for t1 in (1, 2, 4, 8, 0) for t2 in (1, 2, 4, 8, 5)]
+    return {"pairs": cases, "expansions": exp, "taq_mama": taq}
+
+
+def pack_golden(ref):
+    rng = random.Random(202)
+    cases = []
+    specs = [(23, 0, 0, [], 18, 256, 0.0, 1.0), (32, 0, 0, [], 18, 256, 0.0, 1.0), (33, 0, 0, [], 18, 256, 0.0, 1.0),
+             (34, 0, 0, [], 18, 256, 0.0, 1.0), (35, 0, 0, [], 18, 256, 0.0, 1.0), (77, 0, 0, [], 18, 256, 0.0, 1.0),
+             (120, 0.05, 0.03, [], 16, 256, 0.0, 1.0), (150, 0, 0, [60], 18, 256, 0.0, 1.0),
+             (151, 0, 0, [60, 61, 62], 18, 256, 0.0, 1.0), (140, 0.1, 0.05, [50, 90], 18, 16, 0.0, 1.0),
+             (160, 0, 0, [], 18, 256, 0.3, 0.7), (161, 0.02, 0, [80], 18, 256, 0.4, 0.6), (90, 0, 0, [0, 1, 89], 10, 256, 0.0, 1.0)]
+    for (L, pd, pn, eos, min_len, thr, gmin, gmax) in specs:
+        s = list(rand_seq(rng, L, p_degen=pd, p_n=pn))
+        for e in eos:
+            s[e] = "-"
+        s = "".join(s)
+        ent = ref.pack(s, 3, thr, gmin, gmax, min_len)
+        cases.append({"seq": s, "index": 3, "degen_thr": thr, "min_gc": gmin, "max_gc": gmax, "min_len": min_len,
+                      "entries": [["%016x" % a, "%016x" % b, loc, idx, st] for (a, b, loc, idx, st) in ent]})
+    return {"cases": cases}
+
+
+def screen_golden(ref):
+    """select_words + find_target_match + compute_coverage on small families."""
+    cases = []
+    for ci, opts in enumerate([dict(), dict(target_threshold=0.9), dict(target_threshold=0.8, use_taq_mama=1),
+                               dict(target_threshold=0.9, optimize_5=1, optimize_3=1),
+                               dict(target_threshold=0.85, amp_min=60, amp_max=300)]):
+        rng = random.Random(303 + ci)
+        seqs = family_targets(rng, 2, 5, 420, div=0.04)
+        seqs.append(rand_seq(rng, 40))
+        seqs.append(rand_seq(rng, 211, p_degen=0.03, p_n=0.02))
+        s = list(seqs[0]); s[200] = "-"; seqs.append("".join(s))
+        weights = [1.0 + 0.37 * (i % 5) for i in range(len(seqs))]
+        pairs_txt = []
+        while len(pairs_txt) < 8:
+            p = sample_pair(rng, rng.choice(seqs[:10]))
+            if p:
+                pairs_txt.append(p)
+        s0 = seqs[1]
+        pairs_txt.append((s0[0:20], revcomp(s0[100:120])))
+        pairs_txt.append((s0[len(s0) - 150:len(s0) - 130], revcomp(s0[len(s0) - 21:])))
+        pairs = [(ref.centered_word(f), ref.centered_word(r)) for f, r in pairs_txt]
+        ses = ref.session(**opts)
+        for q, w in zip(seqs, weights):
+            ses.add_target(q, w)
+        inactive = [3] if ci == 1 else []
+        splits = [[2, 100]] if ci == 1 else []
+        for i in inactive:
+            ses.set_active(i, False)
+        for i, pos in splits:
+            ses.split(i, pos)
+        n = ses.select(pairs)
+        db = ses.db_entries()
+        bits = [ses.target_match(p).tolist() for p in pairs]
+        cov = [float(ses.target_coverage(p)) for p in pairs]
+        cases.append({"options": ses.opts, "seqs": seqs, "weights": weights, "inactive": inactive, "splits": splits,
+                      "pairs": [hexw(f) + hexw(r) for f, r in pairs], "n_entries": n,
+                      "db": [["%016x" % a, "%016x" % b, loc, idx, st] for (a, b, loc, idx, st) in db],
+                      "bits": bits, "coverage": cov})
+    return {"cases": cases}
+
+
+def main():
+    build_reference()
+    ref = Reference()
+    os.makedirs(OUT, exist_ok=True)
+    for name, fn in (("words", words_golden), ("pack", pack_golden), ("screen", screen_golden)):
+        with open(os.path.join(OUT, name + ".json"), "w") as f:
+            json.dump(fn(ref), f, separators=(",", ":"))
+        print("wrote", name, os.path.getsize(os.path.join(OUT, name + ".json")), "bytes")
+
+
+if __name__ == "__main__":
+    main()

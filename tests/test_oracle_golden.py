@@ -1,0 +1,65 @@
+"""The CPU oracle against the committed golden vectors (tests/golden/*.json, captured from the
+compiled reference by oracle/make_golden.py).  Runs anywhere, including the GPU box."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    with open(os.path.join(G, name + ".json")) as f:
+        return json.load(f)
+
+
+def w(h):
+    return (int(h[0], 16), int(h[1], 16))
+
+
+def test_words(oracle):
+    g = load("words")
+    for c in g["pairs"]:
+        a, b = w(c["a"]), w(c["b"])
+        assert oracle.word_and(a, b) == c["and"]
+        assert oracle.word_size(a) == c["size"]
+        assert oracle.word_start(a) == c["start"]
+        assert oracle.word_stop(a) == c["stop"]
+        assert oracle.word_degeneracy(a) == c["degeneracy"]
+        if "center" in c:
+            assert oracle.word_center(a) == w(c["center"])
+            assert oracle.word_complement(a) == w(c["complement"])
+    for e in g["expansions"]:
+        assert oracle.word_expand(w(e["word"])) == [w(x) for x in e["expansion"]]
+    for p1, p2, t1, t2, v in g["taq_mama"]:
+        assert oracle.taq_mama(p1, p2, t1, t2) == np.float32(v)
+
+
+def test_pack(oracle):
+    for c in load("pack")["cases"]:
+        got = oracle.pack(c["seq"], c["index"], c["degen_thr"], c["min_gc"], c["max_gc"], c["min_len"])
+        want = sorted((int(a, 16), int(b, 16), loc, idx, st) for a, b, loc, idx, st in c["entries"])
+        assert got == want
+
+
+def screen_cases():
+    return load("screen")["cases"]
+
+
+@pytest.mark.parametrize("ci", range(5))
+def test_screen(oracle, ci):
+    c = screen_cases()[ci]
+    s = oracle.session(**c["options"])
+    for q, wt in zip(c["seqs"], c["weights"]):
+        s.add_target(q, wt)
+    for i in c["inactive"]:
+        s.set_active(i, False)
+    for i, pos in c["splits"]:
+        s.split(i, pos)
+    pairs = [((int(p[0], 16), int(p[1], 16)), (int(p[2], 16), int(p[3], 16))) for p in c["pairs"]]
+    assert s.select(pairs) == c["n_entries"]
+    assert s.db_entries() == sorted((int(a, 16), int(b, 16), loc, idx, st) for a, b, loc, idx, st in c["db"])
+    for k, p in enumerate(pairs):
+        assert s.target_match(p).tolist() == c["bits"][k]
+        assert s.target_coverage(p) == np.float32(c["coverage"][k])
