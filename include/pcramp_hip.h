@@ -143,6 +143,45 @@ int pcr_profile_read(pcr_ctx *ctx, double *scan_ms, uint64_t *scan_launches, int
 int pcr_synchronize(pcr_ctx *ctx);
 
 
+/* ---- Smith-Waterman primer x template alignment (rows a7/a8 of the scope table) */
+
+/* Outputs of one SO::SeqOverlap lane (seq_overlap.h:1266-1330). */
+typedef struct {
+	int16_t score;              /* SeqOverlap::score() = max_elem.M */
+	int16_t q_start, q_stop;    /* alignment_range_query() */
+	int16_t t_start, t_stop;    /* alignment_range_target() */
+	uint8_t last1, last2;       /* target_last_two_aligned() (15,15 = N,N when undefined) */
+	uint8_t valid;              /* 0: no cell reached the running maximum; the reference leaves the
+	                               coordinates stale then, here they are zero and only score (0) is defined */
+	uint8_t pad;
+} pcr_sw_result;
+
+/* n independent alignments, query word i against template word i, exactly as
+ * SeqOverlap::pack_query_slots / pack_target_slots(Word) + align() (SmithWaterman, nucleic acid)
+ * evaluate one lane (seq_overlap.h:828,1099; seq_overlap.cpp:347-609). */
+int pcr_sw_align_words(pcr_ctx *ctx, const pcr_word128 *queries, const pcr_word128 *templates, uint32_t n,
+	pcr_sw_result *out);
+
+typedef struct {
+	float collect_threshold;     /* background_threshold*background_search_multiplier (assay.h:418); squared inside */
+	float background_threshold;  /* the final score test (background_match.cpp:116) */
+	int32_t amp_min, amp_max;    /* opt.background_amplicon_range */
+	int32_t use_taq_mama;
+} pcr_background_args;
+
+/* PCR::find_background_match (background_match.cpp:7-166) for a batch of pairs against the set's
+ * current word DB: candidate amplicons -> 4 alignments each -> normalised score product ->
+ * bits[pair][seq].  Every candidate amplicon is evaluated (the reference's `(i+1) >= num_seq`
+ * loop test, :122, skips some and can read out of bounds). */
+int pcr_background_match(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_pairs,
+	const pcr_background_args *args, uint64_t *bits);
+
+/* PCR::find_multiplex_background_match (background_match.cpp:168-295): F, (F), R, (R) of every
+ * pair aligned against every whole sequence of the set (amplicon sequences, up to 32767 bases);
+ * bit set when any single normalised score reaches the threshold. */
+int pcr_multiplex_match(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_pairs,
+	float background_threshold, int use_taq_mama, uint64_t *bits);
+
 /* ---- Host-only helpers (pure CPU arithmetic of the host half of the index build; usable
  * without a GPU; exercised by the `not gpu` tests). */
 

@@ -633,3 +633,170 @@ float orc_weighted_coverage(orc_session *s, const unsigned char *bits)          
 }
 
 } // extern "C"
+
+// ------------------------------------------------------------------------------------ Smith-Waterman
+namespace {
+
+struct SWCell { int M, Iq, It, Ms_i, Ms_j, Iqs_i, Iqs_j, Its_i, Its_j; };
+
+// One lane of SeqOverlap::align_smith_waterman (seq_overlap.cpp:347-609): match +2 / mismatch -3
+// on IUPAC intersection, gap open -5, extend -2 (:60-67); start coordinates travel with the
+// scores; the running maximum is taken with !(X.M < max), so ties go to the last cell in
+// row-major order (:583).
+void sw_align(const uint8_t *q, int qlen, const uint8_t *t, int tlen, orc_sw_result *out)
+{
+	const int MATCH = 2, MISMATCH = -3, GAP_OPEN = -5, GAP_EXT = -2;
+	std::vector<SWCell> last(tlen + 1), curr(tlen + 1);
+	for(int j = 0;j <= tlen;++j){                                                 // :383-392
+		SWCell c = {0, GAP_OPEN, GAP_OPEN, 0, j, 0, 0, 0, 0};
+		last[j] = c;
+		SWCell z = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+		curr[j] = z;                                                              // :396 memset
+	}
+	int maxM = 0, max_si = 0, max_sj = 0, stop_i = 0, stop_j = 0;
+	bool touched = false;
+	for(int i = 0;i < qlen;++i){
+		curr[0].M = 0; curr[0].Iq = curr[0].It = GAP_OPEN;                        // :404-411
+		curr[0].Ms_i = i + 1; curr[0].Ms_j = 0;
+		for(int j = 0;j < tlen;++j){
+			const SWCell &A = last[j], &B = last[j + 1], &C = curr[j];
+			SWCell X;
+			const int tmp_c = std::max(std::max(A.M, A.Iq), A.It);                // :436
+			const int s = ((q[i] & t[j]) > 0) ? MATCH : MISMATCH;                 // :440-444
+			X.M = std::max(tmp_c, 0) + s;                                         // :455-458
+			bool m = (A.M < A.Iq) || (A.M < A.It);                                // :483-488
+			X.Ms_i = m ? 0 : A.Ms_i; X.Ms_j = m ? 0 : A.Ms_j;
+			m = !(A.Iq < A.It) && (A.Iq > A.M);                                   // :491-503
+			if(m){ X.Ms_i = A.Iqs_i; X.Ms_j = A.Iqs_j; }
+			m = (A.It > A.M) && (A.It > A.Iq);                                    // :506-518
+			if(m){ X.Ms_i = A.Its_i; X.Ms_j = A.Its_j; }
+			if(0 > tmp_c){ X.Ms_i = i; X.Ms_j = j; }                              // :522-532
+			int tb = std::max(C.M, 0) + GAP_OPEN, tc = std::max(C.Iq, 0) + GAP_EXT;   // :536-553
+			X.Iq = std::max(tb, tc);
+			if(tb < tc){ X.Iqs_i = C.Iqs_i; X.Iqs_j = C.Iqs_j; } else{ X.Iqs_i = C.Ms_i; X.Iqs_j = C.Ms_j; }
+			tb = std::max(B.M, 0) + GAP_OPEN; tc = std::max(B.It, 0) + GAP_EXT;       // :557-574
+			X.It = std::max(tb, tc);
+			if(tb < tc){ X.Its_i = B.Its_i; X.Its_j = B.Its_j; } else{ X.Its_i = B.Ms_i; X.Its_j = B.Ms_j; }
+			if(!(X.M < maxM)){                                                    // :579-603 (i < qlen, j < tlen hold)
+				maxM = X.M; max_si = X.Ms_i; max_sj = X.Ms_j; stop_i = i; stop_j = j; touched = true;
+			}
+			curr[j + 1] = X;
+		}
+		std::swap(last, curr);
+	}
+	out->score = (int16_t)maxM;
+	out->valid = touched ? 1 : 0;
+	out->q_start = (int16_t)max_si; out->q_stop = (int16_t)stop_i;
+	out->t_start = (int16_t)max_sj; out->t_stop = (int16_t)stop_j;
+	out->last1 = out->last2 = 15;                                                 // seq_overlap.h:1266-1286
+	if(touched && stop_j >= 1 && stop_j < tlen){ out->last1 = t[stop_j - 1]; out->last2 = t[stop_j]; }
+	out->pad = 0;
+}
+
+// pack_query_slots / pack_target_slots(Word): size() slots starting at start() (seq_overlap.h:828-857,1099-1125)
+int word_to_codes(const W &w, uint8_t *codes)
+{
+	const int len = (int)w.size();
+	int j = w.start();
+	for(int i = 0;i < len;++i, ++j){ codes[i] = (uint8_t)w.get(j); }
+	return len;
+}
+
+struct SWWordResult { orc_sw_result r; };
+
+void sw_words(const W &q, const W &t, orc_sw_result *out)
+{
+	uint8_t qc[32], tc[32];
+	const int ql = word_to_codes(q, qc), tl = word_to_codes(t, tc);
+	sw_align(qc, ql, tc, tl, out);
+}
+
+} // namespace
+
+extern "C" {
+
+void orc_sw_align(const uint8_t *q, int qlen, const uint8_t *t, int tlen, orc_sw_result *out) { sw_align(q, qlen, t, tlen, out); }
+
+void orc_sw_align_words(const uint64_t q[2], const uint64_t t[2], orc_sw_result *out) { sw_words(load_word(q), load_word(t), out); }
+
+int orc_session_background_match(orc_session *s, const uint64_t pair[4], float bg_threshold, float bg_multiplier,
+	int amp_min, int amp_max, int use_taq_mama, int emulate_index_bug, unsigned char *bits_out)
+{
+	try{
+		const W F = load_word(pair), R = load_word(pair + 2);
+		memset(bits_out, 0, s->seq.size());
+		std::vector<Amplicon> amp;
+		std::map<uint32_t, float> fi, ri;
+		if(!s->keys.empty()){                                                     // assay.h:411-421
+			collect_candidates(amp, fi, ri, F, R, *s, bg_threshold*bg_multiplier, amp_min, amp_max);
+		}
+		float f_norm = 2.0f*F.size(), r_norm = 2.0f*R.size();                     // background_match.cpp:20-29
+		if(f_norm > 0.0f) f_norm = 1.0f/f_norm;
+		if(r_norm > 0.0f) r_norm = 1.0f/r_norm;
+		const W Fc = F.complement(), Rc = R.complement();
+		unsigned fp1 = 0, fp2 = 0, fm1 = 0, fm2 = 0, rp1 = 0, rp2 = 0, rm1 = 0, rm2 = 0;
+		if(use_taq_mama){                                                         // :36-42 (get_last_two, word.h:299)
+			fp1 = F.get(F.stop() - 1); fp2 = F.get(F.stop());
+			fm1 = Fc.get(Fc.stop() - 1); fm2 = Fc.get(Fc.stop());
+			rp1 = R.get(R.stop() - 1); rp2 = R.get(R.stop());
+			rm1 = Rc.get(Rc.stop() - 1); rm2 = Rc.get(Rc.stop());
+		}
+		for(size_t k = 0;k < amp.size();++k){                                     // :66-164, one amplicon per 4 lanes
+			const Amplicon &a = amp[k];
+			// background_match.cpp:122 tests `(i+1) >= num_seq` (not the amplicon count): the odd-indexed
+			// amplicon i+1 is silently skipped once i+1 reaches the number of SEQUENCES.  Reproduced only
+			// on request, to pin this restatement against the compiled reference.
+			if(emulate_index_bug && (k & 1) && k >= s->seq.size()) continue;
+			orc_sw_result l0, l1, l2, l3;
+			sw_words(F, s->keys[a.f], &l0);                                       // slot 0: F   + f[i]
+			sw_words(Fc, s->keys[a.f], &l1);                                      // slot 1: (F) + f[i]
+			sw_words(R, s->keys[a.r], &l2);                                       // slot 2: R   + r[i]
+			sw_words(Rc, s->keys[a.r], &l3);                                      // slot 3: (R) + r[i]
+			float FpRm = l0.score*l3.score*f_norm*r_norm;                         // :82-83 (int product, then float)
+			float RpFm = l1.score*l2.score*f_norm*r_norm;
+			if(use_taq_mama){                                                     // :85-93
+				FpRm *= taq_mama(fp1, fp2, l0.last1, l0.last2)*taq_mama(rm1, rm2, l3.last1, l3.last2);
+				RpFm *= taq_mama(rp1, rp2, l2.last1, l2.last2)*taq_mama(fm1, fm2, l1.last1, l1.last2);
+			}
+			float score;
+			if(FpRm > RpFm) score = sqrt(FpRm); else score = sqrt(RpFm);          // :100-113 (double sqrt, stored as float)
+			if(score >= bg_threshold) bits_out[a.index] = 1;                      // :116-120
+		}
+		return 0;
+	}
+	catch(const char *e){ s->err = e; return -1; }
+}
+
+int orc_session_multiplex_match(orc_session *s, const uint64_t pair[4], float bg_threshold, int use_taq_mama,
+	unsigned char *bits_out)
+{
+	const W F = load_word(pair), R = load_word(pair + 2);
+	memset(bits_out, 0, s->seq.size());
+	float f_norm = 2.0f*F.size(), r_norm = 2.0f*R.size();                         // background_match.cpp:179-188
+	if(f_norm > 0.0f) f_norm = 1.0f/f_norm;
+	if(r_norm > 0.0f) r_norm = 1.0f/r_norm;
+	const W Fc = F.complement(), Rc = R.complement();
+	const W *oligo[4] = {&F, &Fc, &R, &Rc};
+	uint8_t qc[4][32]; int ql[4];
+	for(int k = 0;k < 4;++k) ql[k] = word_to_codes(*oligo[k], qc[k]);
+	for(size_t i = 0;i < s->seq.size();++i){                                      // :224-294
+		const Seq &q = s->seq[i];
+		std::vector<uint8_t> t(q.len);
+		for(uint64_t p = 0;p < q.len;++p) t[p] = (uint8_t)q.at(p);
+		bool hit = false;
+		for(int k = 0;k < 4;++k){
+			orc_sw_result r;
+			sw_align(qc[k], ql[k], t.data(), (int)q.len, &r);
+			float sc = r.score*((k < 2) ? f_norm : r_norm);                       // :244-248
+			if(use_taq_mama){                                                     // :250-257
+				const W &o = *oligo[k];
+				sc *= taq_mama(o.get(o.stop() - 1), o.get(o.stop()), r.last1, r.last2);
+			}
+			if(sc >= bg_threshold) hit = true;                                    // :260-267
+		}
+		if(hit) bits_out[i] = 1;
+	}
+	return 0;
+}
+
+} // extern "C"

@@ -80,6 +80,35 @@ float orc_session_target_coverage(orc_session *s, const uint64_t pair[4]);
 // main.cpp:1402-1418
 float orc_weighted_coverage(orc_session *s, const unsigned char *bits);
 
+// ---- Smith-Waterman (SO::SeqOverlap, SmithWaterman + nucleic-acid mode; seq_overlap.cpp:347-609)
+typedef struct {
+	int16_t score;              // max_elem.M                      (seq_overlap.h:1321)
+	int16_t q_start, q_stop;    // alignment_range_query           (seq_overlap.h:1289)
+	int16_t t_start, t_stop;    // alignment_range_target          (seq_overlap.h:1301)
+	uint8_t last1, last2;       // target_last_two_aligned         (seq_overlap.h:1266)
+	uint8_t valid;              // 0: no cell reached the running maximum (the reference then leaves
+	                            //    the coordinates stale; only `score` is defined)
+	uint8_t pad;
+} orc_sw_result;
+// one lane: q/t are arrays of 4-bit codes
+void orc_sw_align(const uint8_t *q, int qlen, const uint8_t *t, int tlen, orc_sw_result *out);
+// pack_query_slots / pack_target_slots(Word) (seq_overlap.h:828,1099) then align
+void orc_sw_align_words(const uint64_t q[2], const uint64_t t[2], orc_sw_result *out);
+// PCR::find_background_match (background_match.cpp:7-166) over the session's sequences used as
+// the background set (the DB must have been built with orc_session_select at
+// background_threshold*multiplier and 0.9x min length, main.cpp:592-601).  Every candidate
+// amplicon is evaluated.  The reference's loop tests `(i+1) >= num_seq` instead of the amplicon
+// count (:122): it skips odd-indexed amplicons once their index reaches the number of sequences
+// and, for an odd count below that, reads stale lanes and indexes past its deque.
+// emulate_index_bug != 0 reproduces the skip (used only to pin this restatement against the
+// compiled reference); the product implements emulate_index_bug == 0.  See DESIGN.md.
+int orc_session_background_match(orc_session *s, const uint64_t pair[4], float bg_threshold, float bg_multiplier,
+	int amp_min, int amp_max, int use_taq_mama, int emulate_index_bug, unsigned char *bits_out);
+// PCR::find_multiplex_background_match (background_match.cpp:168-295): the four oligo
+// orientations against every sequence of the session (no DB needed).
+int orc_session_multiplex_match(orc_session *s, const uint64_t pair[4], float bg_threshold, int use_taq_mama,
+	unsigned char *bits_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,7 +28,20 @@
 #include <vector>
 #include <deque>
 
+#include <iostream>
+#include <ostream>
+#include <math.h>
+#include <unordered_map>
+#include <unordered_set>
+#include <list>
+#include <set>
+#include <algorithm>
+
+// The candidate-amplicon count of PCR::collect_background_candidates is private; the harness
+// needs it only to refuse the reference's odd-count out-of-bounds read (background_match.cpp:122).
+#define private public
 #include "assay.h"        // reference header (pulls pcramp.h, sequence.h, word.h, nuc_cruc.h)
+#undef private
 #include "seq_overlap.h"  // reference header
 
 using namespace std;
@@ -352,6 +365,63 @@ int ref_sw_align_words(const uint64_t *query_words, const uint64_t *target_words
 	}
 	catch(const char *e){ return -1; }
 	catch(...){ return -2; }
+}
+
+
+// PCR::find_background_match (background_match.cpp:7) with the session's sequences as the
+// background set.  Returns the candidate amplicon count, or -3 WITHOUT evaluating when that
+// count is odd and smaller than the number of sequences: the reference then reads lanes 4-7 of a
+// previous iteration and indexes past its amplicon deque (background_match.cpp:122).
+long ref_session_background_match(RefSession *s, const uint64_t pair[4], float bg_threshold, float bg_multiplier,
+	int amp_min, int amp_max, int use_taq_mama, unsigned char *bits_out)
+{
+	try{
+		Options opt = s->opt;
+		opt.background_threshold = bg_threshold;
+		opt.background_search_multiplier = bg_multiplier;
+		opt.background_amplicon_range = make_pair(amp_min, amp_max);
+		opt.use_taq_mama = (use_taq_mama != 0);
+		PCR p;
+		p.oligo( FORWARD, word_from(pair) );
+		p.oligo( REVERSE, word_from(pair + 2) );
+		p.collect_background_candidates(s->target_keys, s->target_db, s->target_seq, opt);
+		const long n_amp = (long)p.background_amplicons.size();
+		const size_t n = s->target_seq.size();
+		memset(bits_out, 0, n);
+		if( (n_amp & 1) && ( (size_t)n_amp < n ) ){
+			return -3;
+		}
+		BitSet m(n, false);
+		p.find_background_match(m, s->target_keys, s->target_db, s->target_seq, opt, cerr);
+		for(size_t i = 0;i < n;++i){
+			bits_out[i] = m[i] ? 1 : 0;
+		}
+		return n_amp;
+	}
+	catch(const char *e){ s->last_error = e; return -1; }
+	catch(...){ s->last_error = "unknown"; return -2; }
+}
+
+int ref_session_multiplex_match(RefSession *s, const uint64_t pair[4], float bg_threshold, int use_taq_mama,
+	unsigned char *bits_out)
+{
+	try{
+		Options opt = s->opt;
+		opt.background_threshold = bg_threshold;
+		opt.use_taq_mama = (use_taq_mama != 0);
+		PCR p;
+		p.oligo( FORWARD, word_from(pair) );
+		p.oligo( REVERSE, word_from(pair + 2) );
+		const size_t n = s->target_seq.size();
+		BitSet m(n, false);
+		p.find_multiplex_background_match(m, s->target_seq, opt, cerr);
+		for(size_t i = 0;i < n;++i){
+			bits_out[i] = m[i] ? 1 : 0;
+		}
+		return 0;
+	}
+	catch(const char *e){ s->last_error = e; return -1; }
+	catch(...){ s->last_error = "unknown"; return -2; }
 }
 
 // ---------------------------------------------------------------- NucCruc thermodynamics

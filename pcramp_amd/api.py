@@ -40,6 +40,16 @@ class _Entry(C.Structure):
                 ("pad", C.c_uint32)]
 
 
+class SwResult(C.Structure):
+    _fields_ = [("score", C.c_int16), ("q_start", C.c_int16), ("q_stop", C.c_int16), ("t_start", C.c_int16),
+                ("t_stop", C.c_int16), ("last1", C.c_uint8), ("last2", C.c_uint8), ("valid", C.c_uint8), ("pad", C.c_uint8)]
+
+
+class BackgroundArgs(C.Structure):
+    _fields_ = [("collect_threshold", C.c_float), ("background_threshold", C.c_float), ("amp_min", C.c_int32),
+                ("amp_max", C.c_int32), ("use_taq_mama", C.c_int32)]
+
+
 class AmplifyArgs(C.Structure):
     _fields_ = [("collect_threshold", C.c_float), ("ident_threshold", C.c_float), ("amp_min", C.c_int32),
                 ("amp_max", C.c_int32), ("use_taq_mama", C.c_int32)]
@@ -57,6 +67,7 @@ ABI_SYMBOLS = [
     "pcr_select_words", "pcr_get_entries", "pcr_amplify", "pcr_amplify_device", "pcr_coverage_from_bits",
     "pcr_weighted_coverage", "pcr_num_sequences", "pcr_bitset_words", "pcr_profile_enable", "pcr_profile_read",
     "pcr_synchronize", "pcr_host_irregular_words", "pcr_host_window_valid", "pcr_host_candidates",
+    "pcr_sw_align_words", "pcr_background_match", "pcr_multiplex_match",
 ]
 
 
@@ -96,6 +107,9 @@ def load_library():
     L.pcr_profile_enable.argtypes = [C.c_void_p, C.c_int]
     L.pcr_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
     L.pcr_synchronize.argtypes = [C.c_void_p]
+    L.pcr_sw_align_words.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    L.pcr_background_match.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.POINTER(BackgroundArgs), C.c_void_p]
+    L.pcr_multiplex_match.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_float, C.c_int, C.c_void_p]
     L.pcr_host_irregular_words.restype = C.c_int64
     L.pcr_host_irregular_words.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(_Params), C.c_uint32, C.c_void_p, C.c_uint64]
     L.pcr_host_window_valid.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(_Params), C.c_void_p]
@@ -277,6 +291,37 @@ class Screener:
         """optimize.cpp:61-74: collect at threshold*multiplier (float product), test at threshold."""
         ct = float(np.float32(target_threshold) * np.float32(search_multiplier))
         return self.amplify(pairs, ct, target_threshold, amp_min, amp_max, use_taq_mama, which)[3]
+
+    # -- Smith-Waterman family (SO::SeqOverlap + background_match.cpp)
+    def sw_align_words(self, queries, templates):
+        """SeqOverlap lanes: query word i vs template word i -> structured array of pcr_sw_result."""
+        q = np.array([[w[0], w[1]] for w in queries], dtype=np.uint64).reshape(-1, 2)
+        t = np.array([[w[0], w[1]] for w in templates], dtype=np.uint64).reshape(-1, 2)
+        out = (SwResult * max(len(queries), 1))()
+        self._check(self.L.pcr_sw_align_words(self.h, q.ctypes.data, t.ctypes.data, len(queries), out))
+        return [(r.score, r.q_start, r.q_stop, r.t_start, r.t_stop, r.last1, r.last2, r.valid) for r in out[:len(queries)]]
+
+    def find_background_match(self, pairs, background_threshold=0.8, search_multiplier=0.9, amp_min=0, amp_max=2000,
+                              use_taq_mama=False, which=BACKGROUND):
+        """PCR::find_background_match (background_match.cpp:7) -> bool [n_pairs, n]."""
+        a = pairs if isinstance(pairs, np.ndarray) else W.pairs_array(pairs)
+        P = a.shape[0]
+        nw, n = int(self.bitset_words(which)), self.num_sequences(which)
+        bits = np.zeros((P, nw), np.uint64)
+        ct = float(np.float32(background_threshold) * np.float32(search_multiplier))
+        args = BackgroundArgs(ct, background_threshold, amp_min, amp_max, int(use_taq_mama))
+        self._check(self.L.pcr_background_match(self.h, which, a.ctypes.data, P, C.byref(args), bits.ctypes.data))
+        return np.stack([bits_to_bool(bits[i], n) for i in range(P)]) if P else np.zeros((0, n), bool)
+
+    def find_multiplex_background_match(self, pairs, background_threshold=0.8, use_taq_mama=False, which=BACKGROUND):
+        """PCR::find_multiplex_background_match (background_match.cpp:168) -> bool [n_pairs, n]."""
+        a = pairs if isinstance(pairs, np.ndarray) else W.pairs_array(pairs)
+        P = a.shape[0]
+        nw, n = int(self.bitset_words(which)), self.num_sequences(which)
+        bits = np.zeros((P, nw), np.uint64)
+        self._check(self.L.pcr_multiplex_match(self.h, which, a.ctypes.data, P, background_threshold, int(use_taq_mama),
+                                               bits.ctypes.data))
+        return np.stack([bits_to_bool(bits[i], n) for i in range(P)]) if P else np.zeros((0, n), bool)
 
     def profile(self, on=True):
         self._check(self.L.pcr_profile_enable(self.h, int(on)))

@@ -448,6 +448,8 @@ __global__ void k_pair(const DevEntry *__restrict__ db, uint32_t n, const uint32
 	}
 }
 
+#include "pcr_sw.inc"
+
 // ============================================================================== host state
 template<class T> struct DevBuf {
 	T *p = nullptr; size_t cap = 0;
@@ -478,6 +480,7 @@ struct SeqSet {
 	DevBuf<uint64_t> d_len, d_blk_off, d_nblk_real;
 	DevBuf<uint8_t> d_active;
 	DevBuf<IrrDev> irr;
+	DevBuf<uint8_t> codes; DevBuf<uint64_t> d_code_off; bool have_codes = false;
 	// word DB of the last select
 	bool have_db = false;
 	uint32_t n_entries = 0;
@@ -486,7 +489,7 @@ struct SeqSet {
 	{
 		planes.release(); valid.release(); nib.release(); blk_seq.release(); tile_seq.release(); tile_pos0.release();
 		irr_off.release(); seg_lo.release(); seg_hi.release(); d_len.release(); d_blk_off.release();
-		d_nblk_real.release(); d_active.release(); irr.release(); db.release();
+		d_nblk_real.release(); d_active.release(); irr.release(); db.release(); codes.release(); d_code_off.release();
 	}
 };
 
@@ -508,6 +511,9 @@ struct pcr_ctx {
 	DevBuf<uint8_t> cub_tmp;
 	DevBuf<uint32_t> n_unique;
 	DevBuf<OligoDev> oligos;
+	DevBuf<SwJob> sw_jobs; DevBuf<SwOut> sw_out; DevBuf<uint8_t> sw_q, sw_qlen, sw_t, entry_codes, entry_lens;
+	DevBuf<AmpRec> amp_recs; DevBuf<BgPairDev> bg_pairs;
+	size_t amp_cap = size_t(1) << 20;
 	size_t hit_cap = size_t(1) << 22;
 	// profiling
 	bool prof = false;
@@ -689,7 +695,7 @@ void pcr_destroy(pcr_ctx *ctx)
 	ctx->cand_fwd.release(); ctx->cand_rc.release(); ctx->cand_floor.release(); ctx->best.release();
 	ctx->counters.release(); ctx->mask.release(); ctx->status.release(); ctx->hits.release(); ctx->keys.release();
 	ctx->keys_sorted.release(); ctx->keys_unique.release(); ctx->bits_fr.release(); ctx->bits_rf.release();
-	ctx->cub_tmp.release(); ctx->n_unique.release(); ctx->oligos.release(); ctx->tab.release(); ctx->bias.release();
+	ctx->cub_tmp.release(); ctx->n_unique.release(); ctx->oligos.release(); ctx->tab.release(); ctx->bias.release(); ctx->sw_jobs.release(); ctx->sw_out.release(); ctx->sw_q.release(); ctx->sw_qlen.release(); ctx->sw_t.release(); ctx->entry_codes.release(); ctx->entry_lens.release(); ctx->amp_recs.release(); ctx->bg_pairs.release();
 	if(ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
@@ -713,7 +719,7 @@ int pcr_load_sequences(pcr_ctx *ctx, pcr_set which, const uint8_t *packed4, cons
 	if(n >= (1u << 24)){ g_err = "pcr_load_sequences: at most 2^24-1 sequences per GPU shard"; return PCR_ERR_CAPACITY; }
 	HIP_TRY(hipSetDevice(ctx->device));
 	SeqSet &S = ctx->sets[which];
-	S.have_db = false; S.n_entries = 0;
+	S.have_db = false; S.n_entries = 0; S.have_codes = false;
 	S.n = n;
 	S.packed.assign(n, std::vector<uint8_t>());
 	S.len.assign(lengths, lengths + n);
@@ -838,7 +844,7 @@ int pcr_split(pcr_ctx *ctx, pcr_set which, uint32_t seq, uint64_t pos)
 	S.irr_host[seq].clear();
 	pcrhost::PackedSeq q; q.buf = S.packed[seq].data(); q.len = S.len[seq];
 	if(!pcrhost::irregular_words(q, ctx->filt, S.irr_host[seq])){ g_err = "pcr_split: irregular word overflow"; return PCR_ERR_CAPACITY; }
-	S.have_db = false;
+	S.have_db = false; S.have_codes = false;
 	return upload_irregular(ctx, S);
 }
 
@@ -1123,6 +1129,205 @@ int64_t pcr_host_candidates(const pcr_pair *pairs, uint32_t n_pairs, int optimiz
 		if(floors_out) floors_out[i] = cand[i].floor_;
 	}
 	return (int64_t)cand.size();
+}
+
+} // extern "C"
+
+// ------------------------------------------------------------------ Smith-Waterman entry points
+namespace {
+
+// SeqOverlap::pack_query_slots (seq_overlap.h:828-857): size() codes starting at start()
+int word_codes(const Planes &w, uint8_t *codes)
+{
+	const int len = pcrhost::planes_size(w), start = pcrhost::planes_start(w);
+	for(int k = 0;k < 32;++k) codes[k] = (k < len && start + k < 32) ? (uint8_t)pcrhost::planes_nibble(w, start + k) : 0;
+	return len;
+}
+
+// queries of pair p: 4p + {0: F, 1: (F), 2: R, 3: (R)} and the per-pair constants of background_match.cpp:20-42
+int upload_pair_queries(pcr_ctx *ctx, const pcr_pair *pairs, uint32_t n_pairs)
+{
+	std::vector<uint8_t> q((size_t)n_pairs*4*32), ql((size_t)n_pairs*4);
+	std::vector<BgPairDev> bp(n_pairs);
+	for(uint32_t p = 0;p < n_pairs;++p){
+		const Planes F = pcrhost::planes_of_word(pairs[p].f.w), R = pcrhost::planes_of_word(pairs[p].r.w);
+		const Planes o[4] = {F, pcrhost::planes_revcomp(F), R, pcrhost::planes_revcomp(R)};
+		uint8_t last[4][2];
+		for(int l = 0;l < 4;++l){
+			ql[(size_t)p*4 + l] = (uint8_t)word_codes(o[l], &q[((size_t)p*4 + l)*32]);
+			const int stop = pcrhost::planes_stop(o[l]);                          // Word::get_last_two, word.h:299
+			last[l][0] = (stop >= 1) ? (uint8_t)pcrhost::planes_nibble(o[l], stop - 1) : 0;
+			last[l][1] = (stop >= 0) ? (uint8_t)pcrhost::planes_nibble(o[l], stop) : 0;
+		}
+		BgPairDev b;
+		float f_norm = 2.0f*(unsigned)pcrhost::planes_size(F), r_norm = 2.0f*(unsigned)pcrhost::planes_size(R);   // PERFECT_MATCH_SCORE, assay.h:15
+		if(f_norm > 0.0f) f_norm = 1.0f/f_norm;
+		if(r_norm > 0.0f) r_norm = 1.0f/r_norm;
+		b.f_norm = f_norm; b.r_norm = r_norm;
+		b.fp1 = last[0][0]; b.fp2 = last[0][1]; b.fm1 = last[1][0]; b.fm2 = last[1][1];
+		b.rp1 = last[2][0]; b.rp2 = last[2][1]; b.rm1 = last[3][0]; b.rm2 = last[3][1];
+		bp[p] = b;
+	}
+	int rc;
+	if((rc = ctx->sw_q.ensure(q.size())) != PCR_OK) return rc;
+	if((rc = ctx->sw_qlen.ensure(ql.size())) != PCR_OK) return rc;
+	if((rc = ctx->bg_pairs.ensure(bp.size())) != PCR_OK) return rc;
+	HIP_TRY(hipMemcpyAsync(ctx->sw_q.p, q.data(), q.size(), hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(hipMemcpyAsync(ctx->sw_qlen.p, ql.data(), ql.size(), hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(hipMemcpyAsync(ctx->bg_pairs.p, bp.data(), bp.size()*sizeof(BgPairDev), hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	return PCR_OK;
+}
+
+int launch_sw(pcr_ctx *ctx, uint64_t n_jobs, const uint8_t *d_tcodes)
+{
+	if(n_jobs == 0) return PCR_OK;
+	if(n_jobs >= (uint64_t(1) << 31)){ g_err = "too many alignment jobs in one call"; return PCR_ERR_CAPACITY; }
+	int rc;
+	if((rc = ctx->sw_out.ensure(n_jobs)) != PCR_OK) return rc;
+	const unsigned jobs_per_block = SW_THREADS/32;
+	hipLaunchKernelGGL(k_sw, dim3((unsigned)((n_jobs + jobs_per_block - 1)/jobs_per_block)), dim3(SW_THREADS), 0, ctx->stream,
+		ctx->sw_jobs.p, (uint32_t)n_jobs, ctx->sw_q.p, ctx->sw_qlen.p, d_tcodes, ctx->sw_out.p);
+	HIP_TRY(hipGetLastError());
+	return PCR_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int pcr_sw_align_words(pcr_ctx *ctx, const pcr_word128 *queries, const pcr_word128 *templates, uint32_t n, pcr_sw_result *out)
+{
+	if(!ctx || (n && (!queries || !templates || !out))){ g_err = "pcr_sw_align_words: bad argument"; return PCR_ERR_ARG; }
+	if(n == 0) return PCR_OK;
+	HIP_TRY(hipSetDevice(ctx->device));
+	std::vector<uint8_t> q((size_t)n*32), ql(n), t((size_t)n*32);
+	std::vector<SwJob> jobs(n);
+	for(uint32_t i = 0;i < n;++i){
+		ql[i] = (uint8_t)word_codes(pcrhost::planes_of_word(queries[i].w), &q[(size_t)i*32]);
+		const int tl = word_codes(pcrhost::planes_of_word(templates[i].w), &t[(size_t)i*32]);
+		jobs[i].q = i; jobs[i].tlen = (uint32_t)tl; jobs[i].t_off = (uint64_t)i*32;
+	}
+	int rc;
+	if((rc = ctx->sw_q.ensure(q.size())) != PCR_OK) return rc;
+	if((rc = ctx->sw_qlen.ensure(n)) != PCR_OK) return rc;
+	if((rc = ctx->sw_t.ensure(t.size())) != PCR_OK) return rc;
+	if((rc = ctx->sw_jobs.ensure(n)) != PCR_OK) return rc;
+	HIP_TRY(hipMemcpyAsync(ctx->sw_q.p, q.data(), q.size(), hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(hipMemcpyAsync(ctx->sw_qlen.p, ql.data(), n, hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(hipMemcpyAsync(ctx->sw_t.p, t.data(), t.size(), hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(hipMemcpyAsync(ctx->sw_jobs.p, jobs.data(), n*sizeof(SwJob), hipMemcpyHostToDevice, ctx->stream));
+	if((rc = launch_sw(ctx, n, ctx->sw_t.p)) != PCR_OK) return rc;
+	static_assert(sizeof(SwOut) == sizeof(pcr_sw_result), "result layout");
+	HIP_TRY(hipMemcpyAsync(out, ctx->sw_out.p, n*sizeof(SwOut), hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	return PCR_OK;
+}
+
+int pcr_background_match(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_pairs, const pcr_background_args *args,
+	uint64_t *bits)
+{
+	if(!ctx || !args || (n_pairs && (!pairs || !bits))){ g_err = "pcr_background_match: bad argument"; return PCR_ERR_ARG; }
+	HIP_TRY(hipSetDevice(ctx->device));
+	SeqSet &S = ctx->sets[which];
+	if(!S.have_db){ g_err = "pcr_background_match: no word DB (call pcr_select_words first)"; return PCR_ERR_STATE; }
+	const uint64_t words = (S.n + 63)/64;
+	const size_t total = (size_t)n_pairs*words;
+	if(total) memset(bits, 0, total*sizeof(uint64_t));
+	if(S.n_entries == 0 || n_pairs == 0) return PCR_OK;
+	int rc;
+	// match_words of every oligo against the DB, as collect_candidates (pcr_assay.cpp:31-32)
+	const float thr2 = args->collect_threshold*args->collect_threshold;
+	std::vector<OligoDev> ol(2*(size_t)n_pairs);
+	for(uint32_t i = 0;i < n_pairs;++i){ fill_oligo(ol[2*i], pairs[i].f.w, thr2); fill_oligo(ol[2*i + 1], pairs[i].r.w, thr2); }
+	if((rc = ctx->oligos.ensure(ol.size())) != PCR_OK) return rc;
+	HIP_TRY(hipMemcpyAsync(ctx->oligos.p, ol.data(), ol.size()*sizeof(OligoDev), hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	if((rc = upload_pair_queries(ctx, pairs, n_pairs)) != PCR_OK) return rc;
+	const uint32_t mask_words = (2*n_pairs + 31)/32;
+	if((rc = ctx->mask.ensure((size_t)S.n_entries*mask_words)) != PCR_OK) return rc;
+	if((rc = ctx->status.ensure(1)) != PCR_OK) return rc;
+	if((rc = ctx->counters.ensure(4)) != PCR_OK) return rc;
+	if((rc = ctx->bits_fr.ensure(total)) != PCR_OK) return rc;
+	const unsigned threads = 128;
+	const unsigned grid = (S.n_entries + threads - 1)/threads;
+	hipLaunchKernelGGL(k_match, dim3(grid), dim3(threads), 0, ctx->stream, S.db.p, S.n_entries, ctx->oligos.p, 2*n_pairs, mask_words, ctx->mask.p);
+	HIP_TRY(hipGetLastError());
+	uint32_t n_amp = 0, status = 0;
+	for(int attempt = 0;;++attempt){
+		if((rc = ctx->amp_recs.ensure(ctx->amp_cap)) != PCR_OK) return rc;
+		HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, 4*sizeof(uint32_t), ctx->stream));
+		HIP_TRY(hipMemsetAsync(ctx->status.p, 0, sizeof(uint32_t), ctx->stream));
+		hipLaunchKernelGGL(k_pair_emit, dim3(grid), dim3(threads), 0, ctx->stream, S.db.p, S.n_entries, S.seg_hi.p, ctx->mask.p, mask_words,
+			ctx->oligos.p, n_pairs, S.planes.p, S.d_blk_off.p, S.d_len.p, S.d_active.p, args->amp_min, args->amp_max,
+			ctx->amp_recs.p, (uint32_t)ctx->amp_cap, ctx->counters.p, ctx->status.p);
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipMemcpyAsync(&n_amp, ctx->counters.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(hipMemcpyAsync(&status, ctx->status.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(hipStreamSynchronize(ctx->stream));
+		if(n_amp <= ctx->amp_cap) break;
+		if(attempt >= 4 || n_amp > (1u << 29)){ g_err = "pcr_background_match: candidate amplicon list does not fit"; return PCR_ERR_CAPACITY; }
+		ctx->amp_cap = (size_t)n_amp + (n_amp >> 3);
+	}
+	if(status & 1u){ g_err = "Sequence::has_split: range is out of bounds"; return PCR_ERR_RANGE; }
+	if(n_amp == 0) return PCR_OK;
+	if((rc = ctx->entry_codes.ensure((size_t)S.n_entries*32)) != PCR_OK) return rc;
+	if((rc = ctx->entry_lens.ensure(S.n_entries)) != PCR_OK) return rc;
+	if((rc = ctx->sw_jobs.ensure((size_t)n_amp*4)) != PCR_OK) return rc;
+	hipLaunchKernelGGL(k_entry_codes, dim3((S.n_entries*32 + 255)/256), dim3(256), 0, ctx->stream, S.db.p, S.n_entries, ctx->entry_codes.p, ctx->entry_lens.p);
+	HIP_TRY(hipGetLastError());
+	hipLaunchKernelGGL(k_bg_jobs, dim3((n_amp*4 + 255)/256), dim3(256), 0, ctx->stream, ctx->amp_recs.p, n_amp, ctx->entry_lens.p, ctx->sw_jobs.p);
+	HIP_TRY(hipGetLastError());
+	if((rc = launch_sw(ctx, (uint64_t)n_amp*4, ctx->entry_codes.p)) != PCR_OK) return rc;
+	HIP_TRY(hipMemsetAsync(ctx->bits_fr.p, 0, total*sizeof(uint64_t), ctx->stream));
+	hipLaunchKernelGGL(k_bg_score, dim3((n_amp + 255)/256), dim3(256), 0, ctx->stream, ctx->amp_recs.p, n_amp, ctx->sw_out.p, ctx->bg_pairs.p,
+		args->background_threshold, args->use_taq_mama, ctx->bits_fr.p, words);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(bits, ctx->bits_fr.p, total*sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	return PCR_OK;
+}
+
+int pcr_multiplex_match(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_pairs, float background_threshold,
+	int use_taq_mama, uint64_t *bits)
+{
+	if(!ctx || (n_pairs && (!pairs || !bits))){ g_err = "pcr_multiplex_match: bad argument"; return PCR_ERR_ARG; }
+	HIP_TRY(hipSetDevice(ctx->device));
+	SeqSet &S = ctx->sets[which];
+	const uint64_t words = (S.n + 63)/64;
+	const size_t total = (size_t)n_pairs*words;
+	if(total) memset(bits, 0, total*sizeof(uint64_t));
+	if(S.n == 0 || n_pairs == 0) return PCR_OK;
+	int rc;
+	std::vector<uint64_t> code_off(S.n);
+	uint64_t tot = 0;
+	for(uint32_t s = 0;s < S.n;++s){
+		if(S.len[s] > 32767){ g_err = "pcr_multiplex_match: template longer than 32767 bases (SeqOverlap's int16 coordinate range)"; return PCR_ERR_CAPACITY; }
+		code_off[s] = tot; tot += S.len[s];
+	}
+	if(!S.have_codes){
+		if((rc = S.codes.ensure(tot + 64)) != PCR_OK) return rc;
+		if((rc = S.d_code_off.ensure(S.n)) != PCR_OK) return rc;
+		HIP_TRY(hipMemcpyAsync(S.d_code_off.p, code_off.data(), S.n*sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+		HIP_TRY(hipStreamSynchronize(ctx->stream));
+		hipLaunchKernelGGL(k_seq_codes, dim3(8, S.n), dim3(256), 0, ctx->stream, S.nib.p, S.d_blk_off.p, S.d_len.p, S.d_code_off.p, S.n, S.codes.p);
+		HIP_TRY(hipGetLastError());
+		S.have_codes = true;
+	}
+	if((rc = upload_pair_queries(ctx, pairs, n_pairs)) != PCR_OK) return rc;
+	const uint64_t n_jobs = (uint64_t)n_pairs*S.n*4;
+	if((rc = ctx->sw_jobs.ensure(n_jobs)) != PCR_OK) return rc;
+	if((rc = ctx->bits_fr.ensure(total)) != PCR_OK) return rc;
+	hipLaunchKernelGGL(k_mx_jobs, dim3((unsigned)((n_jobs + 255)/256)), dim3(256), 0, ctx->stream, n_pairs, S.n, S.d_len.p, S.d_code_off.p, ctx->sw_jobs.p);
+	HIP_TRY(hipGetLastError());
+	if((rc = launch_sw(ctx, n_jobs, S.codes.p)) != PCR_OK) return rc;
+	HIP_TRY(hipMemsetAsync(ctx->bits_fr.p, 0, total*sizeof(uint64_t), ctx->stream));
+	hipLaunchKernelGGL(k_mx_score, dim3((unsigned)(((uint64_t)n_pairs*S.n + 255)/256)), dim3(256), 0, ctx->stream, n_pairs, S.n, ctx->sw_out.p,
+		ctx->bg_pairs.p, background_threshold, use_taq_mama, ctx->bits_fr.p, words);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(bits, ctx->bits_fr.p, total*sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	return PCR_OK;
 }
 
 } // extern "C"

@@ -21,6 +21,14 @@ class Entry(C.Structure):
                 ("strand", C.c_uint32), ("pad", C.c_uint32)]
 
 
+class SWResult(C.Structure):
+    _fields_ = [("score", C.c_int16), ("q_start", C.c_int16), ("q_stop", C.c_int16), ("t_start", C.c_int16),
+                ("t_stop", C.c_int16), ("last1", C.c_uint8), ("last2", C.c_uint8), ("valid", C.c_uint8), ("pad", C.c_uint8)]
+
+    def tup(self):
+        return (self.score, self.q_start, self.q_stop, self.t_start, self.t_stop, self.last1, self.last2)
+
+
 class OrcOptions(C.Structure):
     _fields_ = [("target_threshold", C.c_float), ("search_multiplier", C.c_float),
                 ("amp_min", C.c_int32), ("amp_max", C.c_int32), ("use_taq_mama", C.c_int32),
@@ -158,6 +166,24 @@ class Oracle(_Lib):
         self.lib.orc_session_add_target_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_float, C.c_int]
         self.lib.orc_weighted_coverage.restype = C.c_float
         self.lib.orc_weighted_coverage.argtypes = [C.c_void_p, C.c_void_p]
+        self.lib.orc_sw_align.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(SWResult)]
+        self.lib.orc_sw_align_words.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(SWResult)]
+        self.lib.orc_session_background_match.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int,
+                                                          C.c_int, C.c_int, C.c_int, C.c_void_p]
+        self.lib.orc_session_multiplex_match.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p]
+
+    def sw_align_codes(self, q, t):
+        """q, t: uint8 arrays of 4-bit codes -> SWResult."""
+        q = np.ascontiguousarray(q, dtype=np.uint8)
+        t = np.ascontiguousarray(t, dtype=np.uint8)
+        r = SWResult()
+        self.lib.orc_sw_align(q.ctypes.data, q.size, t.ctypes.data, t.size, C.byref(r))
+        return r
+
+    def sw_align_words(self, q, t):
+        r = SWResult()
+        self.lib.orc_sw_align_words(_w(q), _w(t), C.byref(r))
+        return r
 
 
 class Reference(_Lib):
@@ -170,6 +196,26 @@ class Reference(_Lib):
         self.lib.ref_session_set_options.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_int,
                                                      C.c_int, C.c_uint, C.c_float, C.c_float, C.c_int,
                                                      C.c_int, C.c_int]
+        self.lib.ref_session_background_match.restype = C.c_long
+        self.lib.ref_session_background_match.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int,
+                                                          C.c_int, C.c_int, C.c_void_p]
+        self.lib.ref_session_multiplex_match.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p]
+        self.lib.ref_sw_align_words.argtypes = [C.c_void_p] * 6
+
+    def sw_align_words8(self, queries, targets):
+        """One 8-lane SeqOverlap call: lists of 8 query words / 8 target words -> list of 8 tuples
+        (score, q_start, q_stop, t_start, t_stop, last1, last2)."""
+        q = np.array([[w[0], w[1]] for w in queries], dtype=np.uint64)
+        t = np.array([[w[0], w[1]] for w in targets], dtype=np.uint64)
+        score = np.zeros(8, np.int16)
+        qr = np.zeros(16, np.int32)
+        tr = np.zeros(16, np.int32)
+        l2 = np.zeros(16, np.uint8)
+        rc = self.lib.ref_sw_align_words(q.ctypes.data, t.ctypes.data, score.ctypes.data, qr.ctypes.data,
+                                         tr.ctypes.data, l2.ctypes.data)
+        assert rc == 0
+        return [(int(score[i]), int(qr[2 * i]), int(qr[2 * i + 1]), int(tr[2 * i]), int(tr[2 * i + 1]),
+                 int(l2[2 * i]), int(l2[2 * i + 1])) for i in range(8)]
 
     @classmethod
     def available(cls):
@@ -262,6 +308,33 @@ class Session:
     def target_coverage(self, pair):
         a = pairs_array([pair])
         return self.f("session_target_coverage")(self.h, a.ctypes.data)
+
+    def background_match(self, pair, bg_threshold=0.8, bg_multiplier=0.9, amp_min=0, amp_max=2000, use_taq_mama=0,
+                         emulate_index_bug=0):
+        """-> (bits uint8[n], n_amplicons or None).  Reference: returns None bits when the reference's
+        odd-count out-of-bounds path would be hit."""
+        a = pairs_array([pair])
+        bits = np.zeros(self.n, dtype=np.uint8)
+        if isinstance(self.L, Oracle):
+            rc = self.L.lib.orc_session_background_match(self.h, a.ctypes.data, bg_threshold, bg_multiplier, amp_min,
+                                                         amp_max, use_taq_mama, emulate_index_bug, bits.ctypes.data)
+            if rc != 0:
+                raise RuntimeError(self.f("session_error")(self.h))
+            return bits, None
+        n = self.L.lib.ref_session_background_match(self.h, a.ctypes.data, bg_threshold, bg_multiplier, amp_min,
+                                                    amp_max, use_taq_mama, bits.ctypes.data)
+        if n == -3:
+            return None, None
+        if n < 0:
+            raise RuntimeError(self.f("session_error")(self.h))
+        return bits, n
+
+    def multiplex_match(self, pair, bg_threshold=0.8, use_taq_mama=0):
+        a = pairs_array([pair])
+        bits = np.zeros(self.n, dtype=np.uint8)
+        fn = self.L.lib.orc_session_multiplex_match if isinstance(self.L, Oracle) else self.L.lib.ref_session_multiplex_match
+        assert fn(self.h, a.ctypes.data, bg_threshold, use_taq_mama, bits.ctypes.data) == 0
+        return bits
 
     def weighted_coverage(self, bits):
         assert isinstance(self.L, Oracle)

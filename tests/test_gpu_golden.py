@@ -17,7 +17,7 @@ def test_screen_golden(ci):
     with open(os.path.join(G, "screen.json")) as f:
         c = json.load(f)["cases"][ci]
     o = c["options"]
-    d = api.Screener(0, o["pack_max_degen"], o["pack_min_gc"], o["pack_max_gc"])
+    d = api.Screener(0, pack_max_degen=o["pack_max_degen"], pack_min_gc=o["pack_min_gc"], pack_max_gc=o["pack_max_gc"])
     d.load_texts(c["seqs"], c["weights"])
     active = np.ones(len(c["seqs"]), np.uint8)
     for i in c["inactive"]:

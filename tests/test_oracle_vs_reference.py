@@ -7,7 +7,7 @@ import random
 import numpy as np
 import pytest
 
-from testdata import rand_seq, family_targets, sample_pair, mutate
+from testdata import rand_seq, family_targets, sample_pair, mutate, revcomp
 
 pytestmark = pytest.mark.usefixtures("reference")
 
@@ -158,3 +158,105 @@ def test_inactive_and_split(oracle, reference):
     for p in pairs:
         assert (so.target_match(p) == sr.target_match(p)).all()
         assert so.target_coverage(p) == sr.target_coverage(p)
+
+
+# ------------------------------------------------------------------------------------ Smith-Waterman
+def test_sw_lanes(oracle, reference):
+    """8-lane SeqOverlap calls (as background_match.cpp drives them) vs the scalar restatement."""
+    rng = random.Random(31)
+    nz = 0
+    for it in range(400):
+        qs, ts = [], []
+        for lane in range(8):
+            qtxt = rand_seq(rng, rng.randint(8, 32), p_degen=0.05)
+            mode = rng.random()
+            if mode < 0.5:       # a noisy copy of the query embedded in the target
+                core = mutate(rng, qtxt, 0.12)
+                if rng.random() < 0.4 and len(core) > 6:   # indel
+                    k = rng.randrange(2, len(core) - 2)
+                    core = core[:k] + (rand_seq(rng, 1) if rng.random() < 0.5 else "") + core[k + (rng.random() < 0.5):]
+                core = core[:32]
+                left = rng.randint(0, 32 - len(core))
+                ttxt = (rand_seq(rng, left) + core + rand_seq(rng, 32))[:rng.randint(min(32, left + len(core)), 32)]
+            elif mode < 0.6:
+                qtxt = "A" * rng.randint(10, 20)
+                ttxt = "A" * rng.randint(10, 32)
+            else:
+                ttxt = rand_seq(rng, rng.randint(8, 32), p_degen=0.05)
+            q = reference.word(qtxt)
+            t = reference.word(ttxt)
+            for _ in range(rng.randint(0, 32 - len(qtxt))):
+                q = reference.word_shift_right(q)
+            for _ in range(rng.randint(0, 32 - len(ttxt))):
+                t = reference.word_shift_right(t)
+            qs.append(q); ts.append(t)
+        want = reference.sw_align_words8(qs, ts)
+        for lane in range(8):
+            got = oracle.sw_align_words(qs[lane], ts[lane])
+            assert got.score == want[lane][0]
+            if got.score > 0:
+                assert got.tup() == want[lane]
+                nz += 1
+    assert nz > 1000
+
+
+def test_sw_known_answers(oracle):
+    """samples captured from the compiled reference."""
+    from pcramp_amd import words as W
+    q = W.codes_from_text("ACGTACGTACGTACGTAC")
+    r = oracle.sw_align_codes(q, W.codes_from_text("TTTTACGTACGTACGTACGTACTTTTTTTTTT"))
+    assert (r.score, r.q_start, r.q_stop, r.t_start, r.t_stop) == (36, 0, 17, 4, 21)
+    r = oracle.sw_align_codes(W.codes_from_text("A" * 18), W.codes_from_text("A" * 32))
+    assert (r.score, r.t_start, r.t_stop) == (36, 14, 31)
+
+
+# find_background_match multiplies a same-strand score with an opposite-strand one (lanes 0x3, 1x2,
+# background_match.cpp:82-83), so realistic thresholds (0.8) rarely fire; lower ones exercise the bit.
+BG_CASES = [dict(bg_threshold=0.8, bg_multiplier=0.9, use_taq_mama=0), dict(bg_threshold=0.45, bg_multiplier=0.9, use_taq_mama=1),
+            dict(bg_threshold=0.4, bg_multiplier=0.8, use_taq_mama=0, amp_max=400), dict(bg_threshold=0.35, bg_multiplier=1.0, use_taq_mama=1)]
+
+
+@pytest.mark.parametrize("kw", BG_CASES)
+def test_background_match(oracle, reference, kw):
+    rng = random.Random(41)
+    roots = family_targets(rng, 3, 1, 700, div=0.0)
+    seqs = []
+    for r in roots:
+        for _ in range(5):
+            seqs.append(mutate(rng, r, 0.05))      # backgrounds: diverged relatives
+    pairs_txt = []
+    while len(pairs_txt) < 20:
+        p = sample_pair(rng, rng.choice(roots))
+        if p:
+            pairs_txt.append(p)
+    pairs = [(reference.centered_word(f), reference.centered_word(r)) for f, r in pairs_txt]
+    thr = np.float32(kw["bg_threshold"]) * np.float32(kw["bg_multiplier"])
+    so, sr = _sessions(oracle, reference, seqs)
+    min_len = int(18 * 0.9)
+    assert so.select(pairs, threshold=thr, min_len_override=min_len) == sr.select(pairs, threshold=thr, min_len_override=min_len)
+    compared = hits = 0
+    for p in pairs:
+        rb, n_amp = sr.background_match(p, **kw)
+        ob, _ = so.background_match(p, emulate_index_bug=1, **kw)
+        if rb is None:
+            continue        # the reference's odd-count out-of-bounds case (background_match.cpp:122)
+        compared += 1
+        hits += int(ob.sum())
+        assert (ob == rb).all()
+    assert compared >= 5 and (hits > 0 or kw["bg_threshold"] > 0.5)
+
+
+@pytest.mark.parametrize("taq", [0, 1])
+def test_multiplex_match(oracle, reference, taq):
+    rng = random.Random(43)
+    base = rand_seq(rng, 400)
+    f, r = base[50:70], revcomp(base[180:202])
+    seqs = [base[40:220], mutate(rng, base[40:220], 0.1), rand_seq(rng, 150), base[60:210], rand_seq(rng, 33),
+            mutate(rng, base[30:230], 0.2), revcomp(base[40:220])]
+    pair = (reference.centered_word(f), reference.centered_word(r))
+    so, sr = _sessions(oracle, reference, seqs)
+    for thr in (0.6, 0.8, 0.95):
+        a = so.multiplex_match(pair, thr, taq)
+        b = sr.multiplex_match(pair, thr, taq)
+        assert (a == b).all()
+    assert so.multiplex_match(pair, 0.8, taq).sum() >= 2
