@@ -109,6 +109,19 @@ int orc_session_background_match(orc_session *s, const uint64_t pair[4], float b
 int orc_session_multiplex_match(orc_session *s, const uint64_t pair[4], float bg_threshold, int use_taq_mama,
 	unsigned char *bits_out);
 
+// ---- nearest-neighbour thermodynamics (NucCruc, nuc_cruc.{h,cpp}) -- pcr_oracle_thermo.cpp
+// out: [0] tm_pm_duplex, [1] dH, [2] dS, [3] dG(37C); [4] hairpin tm, [5] dH, [6] dS; [7] homodimer tm, [8] dH, [9] dS
+int orc_thermo_full(const char *seq, float salt, float strand, float *out);
+// out: tm, dH, dS of approximate_tm_heterodimer with strand(a, b) (nuc_cruc.h:818)
+int orc_heterodimer_full(const char *a, const char *b, float salt, float strand_a, float strand_b, float *out);
+// PCR::is_valid (valid_pcr.cpp:5-45): 1 pass, 0 fail
+int orc_is_valid(const uint64_t word[2], float salt, float primer_strand, float tm_min, float tm_max,
+	float max_hairpin, float max_dimer, int check_homo_dimer);
+// PCR::max_dimer_tm (pcr_assay.cpp:232-269)
+float orc_max_dimer_tm(const uint64_t pair[4], float salt, float primer_strand);
+// PCR::multiplex_compatible (pcr_assay.cpp:815-852), a = this assay, b = argument
+int orc_multiplex_compatible(const uint64_t a[4], const uint64_t b[4], float salt, float primer_strand, float max_dimer);
+
 #ifdef __cplusplus
 }
 #endif

@@ -460,4 +460,143 @@ float ref_heterodimer(const char *a, const char *b, float salt, float strand_a, 
 	catch(...){ return -1.0f; }
 }
 
+// ---------------------------------------------------------------- NucCruc, deterministic form
+// NucCruc::trace_back reads m_q[query_len] (one element past the query, nuc_cruc.cpp:1383 with
+// last_i == 0) whenever a path runs into DP row 0; CircleBuffer::operator[] then returns whatever
+// an earlier, longer query left in the ring (or uninitialised memory).  To make the reference a
+// function of its inputs the harness first fills both rings with the dangling-end code E, which
+// pairs with nothing, so the stray column is always trimmed (nuc_cruc.cpp:868-884).
+static void prefill(NucCruc &melt)
+{
+	for(unsigned i = 0;i < MAX_SEQUENCE_LENGTH;++i){   // straight into the rings: push_back_query() refuses E
+		melt.query.push_back(BASE::E);
+		melt.target.push_back(BASE::E);
+	}
+	melt.clear();
+}
+
+// out: [0] tm_pm_duplex, [1] dH, [2] dS, [3] dG; [4] hairpin tm, [5] dH, [6] dS; [7] homodimer tm, [8] dH, [9] dS
+int ref_thermo_full(const char *seq, float salt, float strand, float *out)
+{
+	try{
+		NucCruc melt;
+		prefill(melt);
+		melt.salt(salt);
+		melt.strand(strand);
+		const string s(seq);
+		out[0] = melt.tm_pm_duplex(s); out[1] = melt.delta_H(); out[2] = melt.delta_S(); out[3] = melt.delta_G();
+		melt.set_query(s);
+		out[4] = melt.approximate_tm_hairpin(); out[5] = melt.delta_H(); out[6] = melt.delta_S();
+		out[7] = melt.approximate_tm_homodimer(); out[8] = melt.delta_H(); out[9] = melt.delta_S();
+		return 0;
+	}
+	catch(const char *e){ return -1; }
+	catch(...){ return -2; }
+}
+
+// out: tm, dH, dS
+int ref_heterodimer_full(const char *a, const char *b, float salt, float strand_a, float strand_b, float *out)
+{
+	try{
+		NucCruc melt;
+		prefill(melt);
+		melt.salt(salt);
+		melt.strand(strand_a, strand_b);
+		melt.set_query( string(a) );
+		melt.set_target( string(b) );
+		out[0] = melt.approximate_tm_heterodimer(); out[1] = melt.delta_H(); out[2] = melt.delta_S();
+		return 0;
+	}
+	catch(...){ return -1; }
+}
+
+static void thermo_options(Options &opt, float primer_strand, float tm_min, float tm_max, float max_hairpin, float max_dimer)
+{
+	opt.primer_strand = primer_strand;
+	opt.primer_tm_range = make_pair(tm_min, tm_max);
+	opt.max_hairpin = max_hairpin;
+	opt.max_dimer = max_dimer;
+}
+
+// PCR::is_valid (valid_pcr.cpp:5-45)
+int ref_is_valid(const uint64_t word[2], float salt, float primer_strand, float tm_min, float tm_max,
+	float max_hairpin, float max_dimer, int check_homo_dimer)
+{
+	try{
+		NucCruc melt;
+		prefill(melt);
+		melt.salt(salt);
+		Options opt;
+		thermo_options(opt, primer_strand, tm_min, tm_max, max_hairpin, max_dimer);
+		PCR p;
+		const Word w = word_from(word);
+		return p.is_valid(FORWARD, w, melt, opt, check_homo_dimer != 0) ? 1 : 0;
+	}
+	catch(...){ return -1; }
+}
+
+// PCR::max_dimer_tm (pcr_assay.cpp:232-269)
+float ref_max_dimer_tm(const uint64_t pair[4], float salt, float primer_strand)
+{
+	try{
+		NucCruc melt;
+		prefill(melt);
+		melt.salt(salt);
+		Options opt;
+		opt.primer_strand = primer_strand;
+		PCR p;
+		p.oligo( FORWARD, word_from(pair) );
+		p.oligo( REVERSE, word_from(pair + 2) );
+		return p.max_dimer_tm(melt, opt);
+	}
+	catch(...){ return -1.0f; }
+}
+
+// PCR::multiplex_compatible (pcr_assay.cpp:815-852): this->assay = a, argument = b
+int ref_multiplex_compatible(const uint64_t a[4], const uint64_t b[4], float salt, float primer_strand, float max_dimer)
+{
+	try{
+		NucCruc melt;
+		prefill(melt);
+		melt.salt(salt);
+		Options opt;
+		opt.primer_strand = primer_strand;
+		opt.max_dimer = max_dimer;
+		PCR pa, pb;
+		pa.oligo( FORWARD, word_from(a) ); pa.oligo( REVERSE, word_from(a + 2) );
+		pb.oligo( FORWARD, word_from(b) ); pb.oligo( REVERSE, word_from(b + 2) );
+		return pa.multiplex_compatible(melt, opt, pb) ? 1 : 0;
+	}
+	catch(...){ return -1; }
+}
+
+// The SantaLucia parameter set as the reference initialises it (published values:
+// SantaLucia & Hicks, Annu. Rev. Biophys. Biomol. Struct. 33:415-440, 2004), for
+// oracle/gen_thermo_tables.py.  scalars: init_H, init_S, asymmetric_loop_dS, bulge_AT_closing_S,
+// AT_closing_H, AT_closing_S, symmetry_S, SALT.
+int ref_thermo_tables(float *H, float *S, float *loop_S, float *bulge_S, float *hairpin_S, float *special_H,
+	float *special_S, float *scalars, float *supp, float *supp_salt, unsigned char *wc)
+{
+	NucCruc m;
+	for(int i = 0;i < NUM_BASE_PAIR;++i){
+		for(int j = 0;j < NUM_BASE_PAIR;++j){
+			H[i*NUM_BASE_PAIR + j] = m.param_H[i][j];
+			S[i*NUM_BASE_PAIR + j] = m.param_S[i][j];
+			if(m.param_loop_terminal_H[i][j] != m.param_H[i][j] || m.param_loop_terminal_S[i][j] != m.param_S[i][j] ||
+			   m.param_hairpin_terminal_H[i][j] != m.param_H[i][j] || m.param_hairpin_terminal_S[i][j] != m.param_S[i][j]){
+				return -1;   // the terminal tables are documented copies of H/S (nuc_cruc_santa_lucia.cpp:594-601)
+			}
+		}
+		wc[i] = m.watson_and_crick[i] ? 1 : 0;
+	}
+	for(int i = 0;i <= MAX_LOOP_LENGTH;++i){ loop_S[i] = m.param_loop_S[i]; bulge_S[i] = m.param_bulge_S[i]; hairpin_S[i] = m.param_hairpin_S[i]; }
+	for(int i = 0;i < NucCruc::NUM_SPECIAL_HAIRPIN_LOOP;++i){ special_H[i] = m.param_hairpin_special_H[i]; special_S[i] = m.param_hairpin_special_S[i]; }
+	scalars[0] = m.param_init_H; scalars[1] = m.param_init_S; scalars[2] = m.param_asymmetric_loop_dS;
+	scalars[3] = m.param_bulge_AT_closing_S; scalars[4] = m.param_AT_closing_H; scalars[5] = m.param_AT_closing_S;
+	scalars[6] = m.param_symmetry_S; scalars[7] = m.param_SALT;
+	for(int i = 0;i < NucCruc::NUM_SUPP_PARAM;++i) supp[i] = m.param_supp[i];
+	for(int i = 0;i < NucCruc::NUM_SALT_PARAM;++i) supp_salt[i] = m.param_supp_salt[i];
+	return NucCruc::NUM_SPECIAL_HAIRPIN_LOOP;
+}
+
 } // extern "C"

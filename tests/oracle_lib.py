@@ -85,6 +85,12 @@ class _Lib:
         f("session_target_coverage").restype = C.c_float
         f("session_target_coverage").argtypes = [C.c_void_p, C.c_void_p]
         self._f = f
+        f("thermo_full").argtypes = [C.c_char_p, C.c_float, C.c_float, C.c_void_p]
+        f("heterodimer_full").argtypes = [C.c_char_p, C.c_char_p, C.c_float, C.c_float, C.c_float, C.c_void_p]
+        f("is_valid").argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int]
+        f("max_dimer_tm").restype = C.c_float
+        f("max_dimer_tm").argtypes = [C.c_void_p, C.c_float, C.c_float]
+        f("multiplex_compatible").argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float]
 
     # ---- words
     def word(self, s):
@@ -138,6 +144,32 @@ class _Lib:
 
     def taq_mama(self, p1, p2, t1, t2):
         return self._f("taq_mama")(p1, p2, t1, t2)
+
+    # ---- thermodynamics
+    def thermo_full(self, seq, salt=0.05, strand=9e-7):
+        out = np.zeros(10, np.float32)
+        rc = self._f("thermo_full")(seq.encode(), salt, strand, out.ctypes.data)
+        assert rc == 0, rc
+        return out
+
+    def heterodimer_full(self, a, b, salt=0.05, strand_a=9e-7, strand_b=9e-7):
+        out = np.zeros(3, np.float32)
+        rc = self._f("heterodimer_full")(a.encode(), b.encode(), salt, strand_a, strand_b, out.ctypes.data)
+        assert rc == 0, rc
+        return out
+
+    def is_valid(self, word, salt=0.05, primer_strand=9e-7, tm_min=50.0, tm_max=75.0, max_hairpin=40.0, max_dimer=40.0,
+                 check_homo_dimer=True):
+        w = _w(word)
+        return self._f("is_valid")(w, salt, primer_strand, tm_min, tm_max, max_hairpin, max_dimer, int(check_homo_dimer))
+
+    def max_dimer_tm(self, pair, salt=0.05, primer_strand=9e-7):
+        a = pairs_array([pair])
+        return self._f("max_dimer_tm")(a.ctypes.data, salt, primer_strand)
+
+    def multiplex_compatible(self, a, b, salt=0.05, primer_strand=9e-7, max_dimer=40.0):
+        x, y = pairs_array([a]), pairs_array([b])
+        return self._f("multiplex_compatible")(x.ctypes.data, y.ctypes.data, salt, primer_strand, max_dimer)
 
     # ---- pack
     def pack(self, seq, index=0, degen_thr=256, min_gc=0.0, max_gc=1.0, min_len=18):

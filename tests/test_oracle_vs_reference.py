@@ -260,3 +260,89 @@ def test_multiplex_match(oracle, reference, taq):
         b = sr.multiplex_match(pair, thr, taq)
         assert (a == b).all()
     assert so.multiplex_match(pair, 0.8, taq).sum() >= 2
+
+
+# ------------------------------------------------------------------------------------ thermodynamics
+def test_thermo_known_values(oracle, reference):
+    """SURVEY.md section 8c samples (salt 0.05, strand 9e-7)."""
+    r = reference.thermo_full("AGAAGGCTCGCCAAAATAAACG", 0.05, 9e-7)
+    assert abs(r[0] - 59.139496) < 1e-4 and abs(r[1] + 172.899994) < 1e-4
+    o = oracle.thermo_full("AGAAGGCTCGCCAAAATAAACG", 0.05, 9e-7)
+    assert (o == r).all()
+    r = reference.thermo_full("GCGCGCAAAAGCGCGC", 0.05, 9e-7)
+    assert abs(r[4] - 67.163818) < 1e-3 and abs(r[7] - 40.364777) < 1e-3
+    assert (oracle.thermo_full("GCGCGCAAAAGCGCGC", 0.05, 9e-7) == r).all()
+
+
+def hairpin_prone(rng, n):
+    stem = rand_seq(rng, rng.randint(4, 8))
+    loop = rand_seq(rng, rng.randint(3, 7))
+    s = rand_seq(rng, rng.randint(0, 4)) + stem + loop + mutate(rng, revcomp(stem), 0.1) + rand_seq(rng, 8)
+    return s[:n] if len(s) >= 12 else s + rand_seq(rng, 12)
+
+
+def test_thermo_random_oligos(oracle, reference):
+    rng = random.Random(51)
+    worst = 0.0
+    for it in range(3000):
+        n = rng.randint(12, 32)
+        mode = rng.random()
+        if mode < 0.6:
+            s = rand_seq(rng, n)
+        elif mode < 0.8:
+            s = hairpin_prone(rng, n)
+        else:       # low complexity / self-complementary
+            unit = rand_seq(rng, rng.randint(1, 4))
+            s = (unit * 32)[:n]
+        salt = rng.choice([0.05, 0.05, 0.01, 0.2, 1.0])
+        strand = rng.choice([9e-7, 9e-7, 4.5e-7, 1e-6, 2e-8])
+        r = reference.thermo_full(s, salt, strand)
+        o = oracle.thermo_full(s, salt, strand)
+        assert (o == r).all(), (s, salt, strand, o, r)
+
+
+def test_heterodimer_random(oracle, reference):
+    rng = random.Random(52)
+    for it in range(1500):
+        a = rand_seq(rng, rng.randint(12, 30))
+        mode = rng.random()
+        if mode < 0.4:
+            b = rand_seq(rng, rng.randint(12, 30))
+        elif mode < 0.8:     # partially complementary: dimers with mismatches, bulges, dangling ends
+            core = mutate(rng, revcomp(a[rng.randint(0, 5):rng.randint(len(a) - 5, len(a))]), 0.15)
+            if rng.random() < 0.4 and len(core) > 6:
+                k = rng.randrange(2, len(core) - 2)
+                core = core[:k] + rand_seq(rng, rng.randint(0, 2)) + core[k + rng.randint(0, 2):]
+            b = (rand_seq(rng, rng.randint(0, 4)) + core + rand_seq(rng, rng.randint(0, 4)))[:32]
+        else:
+            b = a
+        sa, sb = rng.choice([(9e-7, 9e-7), (9e-7, 4.5e-7), (1e-7, 9e-7)])
+        r = reference.heterodimer_full(a, b, 0.05, sa, sb)
+        o = oracle.heterodimer_full(a, b, 0.05, sa, sb)
+        assert (o == r).all(), (a, b, o, r)
+
+
+def test_is_valid_and_dimer_filters(oracle, reference):
+    rng = random.Random(53)
+    n_pass = 0
+    for it in range(300):
+        s = rand_seq(rng, rng.randint(18, 25), p_degen=0.08 if it % 3 == 0 else 0.0)
+        w = reference.centered_word(s)
+        if reference.word_degeneracy(w) > 16:
+            continue
+        kw = dict(tm_min=rng.choice([45.0, 50.0]), tm_max=rng.choice([65.0, 75.0]), max_hairpin=rng.choice([30.0, 40.0]),
+                  max_dimer=rng.choice([30.0, 40.0]), check_homo_dimer=bool(it & 1))
+        a, b = oracle.is_valid(w, **kw), reference.is_valid(w, **kw)
+        assert a == b, (s, kw)
+        n_pass += a
+    assert 10 < n_pass < 290
+    for it in range(120):
+        f = reference.centered_word(rand_seq(rng, rng.randint(18, 25), p_degen=0.05))
+        r = reference.centered_word(rand_seq(rng, rng.randint(18, 25), p_degen=0.05))
+        if reference.word_degeneracy(f) * reference.word_degeneracy(r) > 64:
+            continue
+        assert oracle.max_dimer_tm((f, r)) == reference.max_dimer_tm((f, r))
+        f2 = reference.centered_word(rand_seq(rng, rng.randint(18, 25)))
+        r2 = reference.centered_word(revcomp(rand_seq(rng, 6) + "ACGTTGCAAT" + rand_seq(rng, 5)))
+        for md in (10.0, 25.0, 40.0):
+            assert oracle.multiplex_compatible((f, r), (f2, r2), max_dimer=md) == reference.multiplex_compatible((f, r), (f2, r2), max_dimer=md)
