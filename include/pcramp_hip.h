@@ -182,6 +182,42 @@ int pcr_background_match(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uin
 int pcr_multiplex_match(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_pairs,
 	float background_threshold, int use_taq_mama, uint64_t *bits);
 
+/* ---- Nearest-neighbour thermodynamics (rows a9/a10 of the scope table) */
+
+/* The `Options` fields the thermodynamic filters read (pcramp.h:21-30). */
+typedef struct {
+	float salt;            /* opt.salt -> NucCruc::salt() (main.cpp:535) */
+	float primer_strand;   /* opt.primer_strand */
+	float tm_min, tm_max;  /* opt.primer_tm_range */
+	float max_hairpin;     /* opt.max_hairpin */
+	float max_dimer;       /* opt.max_dimer */
+} pcr_thermo_args;
+
+typedef struct {
+	uint32_t valid;        /* PCR::is_valid(): every IUPAC expansion passes all enabled tests */
+	uint32_t n_expansions; /* Word::degeneracy() as an integer */
+	float tm, dH, dS;      /* NucCruc::tm_pm_duplex / delta_H / delta_S of the FIRST expansion (Word::begin()) */
+	float hairpin_tm;      /* approximate_tm_hairpin of the first expansion */
+	float homodimer_tm;    /* approximate_tm_homodimer of the first expansion (0 unless check_homo_dimer) */
+	uint32_t pad;
+} pcr_thermo_result;
+
+/* PCR::is_valid (valid_pcr.cpp:5-45) for n oligos: perfect-match duplex Tm in [tm_min, tm_max],
+ * hairpin Tm <= max_hairpin and, if check_homo_dimer, homodimer Tm <= max_dimer, for every
+ * non-degenerate expansion, at strand concentration primer_strand/degeneracy (valid_pcr.cpp:13). */
+int pcr_thermo(pcr_ctx *ctx, const pcr_word128 *oligos, uint32_t n, int check_homo_dimer,
+	const pcr_thermo_args *args, pcr_thermo_result *out);
+
+/* PCR::max_dimer_tm (pcr_assay.cpp:232-269): max heterodimer Tm of F x R over all expansions,
+ * strand(primer_strand/D(F), primer_strand/D(R)) (nuc_cruc.h:818-838). */
+int pcr_dimer(pcr_ctx *ctx, const pcr_pair *pairs, uint32_t n, const pcr_thermo_args *args, float *max_tm);
+
+/* PCR::multiplex_compatible (pcr_assay.cpp:815-852): ok[i] = 1 iff no oligo expansion of assay
+ * a[i] forms a heterodimer with any oligo expansion of assay b[i] at Tm >= max_dimer
+ * (strand = primer_strand, no degeneracy correction). */
+int pcr_multiplex_compatible(pcr_ctx *ctx, const pcr_pair *a, const pcr_pair *b, uint32_t n,
+	const pcr_thermo_args *args, uint8_t *ok);
+
 /* ---- Host-only helpers (pure CPU arithmetic of the host half of the index build; usable
  * without a GPU; exercised by the `not gpu` tests). */
 

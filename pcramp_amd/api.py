@@ -50,6 +50,16 @@ class BackgroundArgs(C.Structure):
                 ("amp_max", C.c_int32), ("use_taq_mama", C.c_int32)]
 
 
+class ThermoArgs(C.Structure):
+    _fields_ = [("salt", C.c_float), ("primer_strand", C.c_float), ("tm_min", C.c_float), ("tm_max", C.c_float),
+                ("max_hairpin", C.c_float), ("max_dimer", C.c_float)]
+
+
+class ThermoResult(C.Structure):
+    _fields_ = [("valid", C.c_uint32), ("n_expansions", C.c_uint32), ("tm", C.c_float), ("dH", C.c_float), ("dS", C.c_float),
+                ("hairpin_tm", C.c_float), ("homodimer_tm", C.c_float), ("pad", C.c_uint32)]
+
+
 class AmplifyArgs(C.Structure):
     _fields_ = [("collect_threshold", C.c_float), ("ident_threshold", C.c_float), ("amp_min", C.c_int32),
                 ("amp_max", C.c_int32), ("use_taq_mama", C.c_int32)]
@@ -68,6 +78,7 @@ ABI_SYMBOLS = [
     "pcr_weighted_coverage", "pcr_num_sequences", "pcr_bitset_words", "pcr_profile_enable", "pcr_profile_read",
     "pcr_synchronize", "pcr_host_irregular_words", "pcr_host_window_valid", "pcr_host_candidates",
     "pcr_sw_align_words", "pcr_background_match", "pcr_multiplex_match",
+    "pcr_thermo", "pcr_dimer", "pcr_multiplex_compatible",
 ]
 
 
@@ -110,6 +121,9 @@ def load_library():
     L.pcr_sw_align_words.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     L.pcr_background_match.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.POINTER(BackgroundArgs), C.c_void_p]
     L.pcr_multiplex_match.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_float, C.c_int, C.c_void_p]
+    L.pcr_thermo.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.POINTER(ThermoArgs), C.c_void_p]
+    L.pcr_dimer.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(ThermoArgs), C.c_void_p]
+    L.pcr_multiplex_compatible.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(ThermoArgs), C.c_void_p]
     L.pcr_host_irregular_words.restype = C.c_int64
     L.pcr_host_irregular_words.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(_Params), C.c_uint32, C.c_void_p, C.c_uint64]
     L.pcr_host_window_valid.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(_Params), C.c_void_p]
@@ -322,6 +336,37 @@ class Screener:
         self._check(self.L.pcr_multiplex_match(self.h, which, a.ctypes.data, P, background_threshold, int(use_taq_mama),
                                                bits.ctypes.data))
         return np.stack([bits_to_bool(bits[i], n) for i in range(P)]) if P else np.zeros((0, n), bool)
+
+    # -- nearest-neighbour thermodynamics (NucCruc + valid_pcr.cpp / pcr_assay.cpp:232,815)
+    @staticmethod
+    def _targs(salt, primer_strand, tm_min, tm_max, max_hairpin, max_dimer):
+        return ThermoArgs(salt, primer_strand, tm_min, tm_max, max_hairpin, max_dimer)
+
+    def is_valid(self, oligos, check_homo_dimer=True, salt=0.05, primer_strand=9e-7, tm_min=50.0, tm_max=75.0,
+                 max_hairpin=40.0, max_dimer=40.0):
+        """PCR::is_valid for a batch of oligo words -> list of ThermoResult-like dicts."""
+        a = np.array([[w[0], w[1]] for w in oligos], dtype=np.uint64).reshape(-1, 2)
+        out = (ThermoResult * max(len(oligos), 1))()
+        args = self._targs(salt, primer_strand, tm_min, tm_max, max_hairpin, max_dimer)
+        self._check(self.L.pcr_thermo(self.h, a.ctypes.data, len(oligos), int(check_homo_dimer), C.byref(args), out))
+        return [dict(valid=bool(r.valid), n=r.n_expansions, tm=np.float32(r.tm), dH=np.float32(r.dH), dS=np.float32(r.dS),
+                     hairpin_tm=np.float32(r.hairpin_tm), homodimer_tm=np.float32(r.homodimer_tm)) for r in out[:len(oligos)]]
+
+    def max_dimer_tm(self, pairs, salt=0.05, primer_strand=9e-7):
+        """PCR::max_dimer_tm for a batch of pairs -> float32 array."""
+        a = pairs if isinstance(pairs, np.ndarray) else W.pairs_array(pairs)
+        out = np.zeros(max(a.shape[0], 1), np.float32)
+        args = self._targs(salt, primer_strand, 0.0, 0.0, 0.0, 0.0)
+        self._check(self.L.pcr_dimer(self.h, a.ctypes.data, a.shape[0], C.byref(args), out.ctypes.data))
+        return out[:a.shape[0]]
+
+    def multiplex_compatible(self, assays_a, assays_b, salt=0.05, primer_strand=9e-7, max_dimer=40.0):
+        """PCR::multiplex_compatible: a[i] (this) against b[i] (argument) -> bool array."""
+        a, b = W.pairs_array(assays_a), W.pairs_array(assays_b)
+        out = np.zeros(max(a.shape[0], 1), np.uint8)
+        args = self._targs(salt, primer_strand, 0.0, 0.0, 0.0, max_dimer)
+        self._check(self.L.pcr_multiplex_compatible(self.h, a.ctypes.data, b.ctypes.data, a.shape[0], C.byref(args), out.ctypes.data))
+        return out[:a.shape[0]].astype(bool)
 
     def profile(self, on=True):
         self._check(self.L.pcr_profile_enable(self.h, int(on)))

@@ -449,6 +449,7 @@ __global__ void k_pair(const DevEntry *__restrict__ db, uint32_t n, const uint32
 }
 
 #include "pcr_sw.inc"
+#include "pcr_thermo.inc"
 
 // ============================================================================== host state
 template<class T> struct DevBuf {
@@ -513,6 +514,7 @@ struct pcr_ctx {
 	DevBuf<OligoDev> oligos;
 	DevBuf<SwJob> sw_jobs; DevBuf<SwOut> sw_out; DevBuf<uint8_t> sw_q, sw_qlen, sw_t, entry_codes, entry_lens;
 	DevBuf<AmpRec> amp_recs; DevBuf<BgPairDev> bg_pairs;
+	DevBuf<thermo::Job> th_jobs; DevBuf<thermo::JobOut> th_out; DevBuf<int> th_dg, th_scratch_i; DevBuf<unsigned short> th_scratch_s;
 	size_t amp_cap = size_t(1) << 20;
 	size_t hit_cap = size_t(1) << 22;
 	// profiling
@@ -679,7 +681,16 @@ pcr_ctx *pcr_create(int device, void *hip_stream, const pcr_params *params)
 	if(const char *v = getenv("PCRAMP_SCAN")){ if(v[0] == '1') ctx->scan_version = 1; }   // A/B: the v1 (per-orientation popcount) scan
 	ctx->filt.max_degen = ctx->params.pack_max_degen;
 	ctx->filt.set_gc(ctx->params.pack_min_gc, ctx->params.pack_max_gc);
-	if(hipMemcpyToSymbol(HIP_SYMBOL(c_taq_mama), h_taq_mama, sizeof(h_taq_mama)) != hipSuccess){
+	if(hipMemcpyToSymbol(HIP_SYMBOL(c_taq_mama), h_taq_mama, sizeof(h_taq_mama)) != hipSuccess ||
+	   hipMemcpyToSymbol(HIP_SYMBOL(thermo::c_H), PCR_NN_H, sizeof(PCR_NN_H)) != hipSuccess ||
+	   hipMemcpyToSymbol(HIP_SYMBOL(thermo::c_S), PCR_NN_S, sizeof(PCR_NN_S)) != hipSuccess ||
+	   hipMemcpyToSymbol(HIP_SYMBOL(thermo::c_loop_S), PCR_LOOP_S, sizeof(PCR_LOOP_S)) != hipSuccess ||
+	   hipMemcpyToSymbol(HIP_SYMBOL(thermo::c_bulge_S), PCR_BULGE_S, sizeof(PCR_BULGE_S)) != hipSuccess ||
+	   hipMemcpyToSymbol(HIP_SYMBOL(thermo::c_hairpin_S), PCR_HAIRPIN_S, sizeof(PCR_HAIRPIN_S)) != hipSuccess ||
+	   hipMemcpyToSymbol(HIP_SYMBOL(thermo::c_special_H), PCR_SPECIAL_H, sizeof(PCR_SPECIAL_H)) != hipSuccess ||
+	   hipMemcpyToSymbol(HIP_SYMBOL(thermo::c_special_S), PCR_SPECIAL_S, sizeof(PCR_SPECIAL_S)) != hipSuccess ||
+	   hipMemcpyToSymbol(HIP_SYMBOL(thermo::c_special_key), PCR_SPECIAL_KEY, sizeof(PCR_SPECIAL_KEY)) != hipSuccess ||
+	   hipMemcpyToSymbol(HIP_SYMBOL(thermo::c_wc), PCR_WC, sizeof(PCR_WC)) != hipSuccess){
 		g_err = "pcr_create: hipMemcpyToSymbol failed"; delete ctx; return nullptr;
 	}
 	return ctx;
@@ -695,7 +706,7 @@ void pcr_destroy(pcr_ctx *ctx)
 	ctx->cand_fwd.release(); ctx->cand_rc.release(); ctx->cand_floor.release(); ctx->best.release();
 	ctx->counters.release(); ctx->mask.release(); ctx->status.release(); ctx->hits.release(); ctx->keys.release();
 	ctx->keys_sorted.release(); ctx->keys_unique.release(); ctx->bits_fr.release(); ctx->bits_rf.release();
-	ctx->cub_tmp.release(); ctx->n_unique.release(); ctx->oligos.release(); ctx->tab.release(); ctx->bias.release(); ctx->sw_jobs.release(); ctx->sw_out.release(); ctx->sw_q.release(); ctx->sw_qlen.release(); ctx->sw_t.release(); ctx->entry_codes.release(); ctx->entry_lens.release(); ctx->amp_recs.release(); ctx->bg_pairs.release();
+	ctx->cub_tmp.release(); ctx->n_unique.release(); ctx->oligos.release(); ctx->tab.release(); ctx->bias.release(); ctx->sw_jobs.release(); ctx->sw_out.release(); ctx->sw_q.release(); ctx->sw_qlen.release(); ctx->sw_t.release(); ctx->entry_codes.release(); ctx->entry_lens.release(); ctx->amp_recs.release(); ctx->bg_pairs.release(); ctx->th_jobs.release(); ctx->th_out.release(); ctx->th_dg.release(); ctx->th_scratch_i.release(); ctx->th_scratch_s.release();
 	if(ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
@@ -1327,6 +1338,215 @@ int pcr_multiplex_match(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipMemcpyAsync(bits, ctx->bits_fr.p, total*sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
 	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	return PCR_OK;
+}
+
+} // extern "C"
+
+// ------------------------------------------------------------------ thermodynamics entry points
+namespace {
+
+// NucCruc::update_dp_param (nuc_cruc.cpp:191-342): the integer dG table of the alignment DP at
+// 37 C for a given salt.  Float arithmetic in the reference's order; log() is the float overload.
+void build_dg_table(float na, int *dg /* [49*49] */)
+{
+	using namespace thermo;
+	auto scale = [](float x){ return (int)(x*10000.0f); };                       // NC_SCORE_SCALE, nuc_cruc.h:235
+	const float sc = PCR_SALT*logf(na);
+	const float loop_sc = sc*PCR_SUPP_SALT[0], bulge_sc = sc*PCR_SUPP_SALT[1];
+	const float match_sc = sc*PCR_SUPP_SALT[2], mismatch_sc = sc*PCR_SUPP_SALT[3];
+	for(int i = 0;i < 49*49;++i) dg[i] = scale(PCR_NN_H[i] - TARGET_T*(PCR_NN_S[i] + sc));
+	for(int i = bA;i <= bI;++i) for(int j = bA;j <= bI;++j){
+		const int curr = i*NB + j;
+		for(int k = bA;k <= bI;++k){
+			const int prev1 = k*NB + bGAP, prev2 = bGAP*NB + k;
+			int v;
+			if(PCR_WC[curr]){
+				if(curr == pAT || curr == pTA) v = scale(PCR_SUPP[4] - TARGET_T*(PCR_SUPP[5] + match_sc));
+				else if(curr == pGC || curr == pCG) v = scale(PCR_SUPP[6] - TARGET_T*(PCR_SUPP[7] + match_sc));
+				else v = scale(PCR_SUPP[8] - TARGET_T*(PCR_SUPP[9] + match_sc));
+			}
+			else v = scale(PCR_SUPP[10] - TARGET_T*(PCR_SUPP[11] + mismatch_sc));
+			v = std::max(0, v);
+			dg[curr*49 + prev1] = dg[prev1*49 + curr] = dg[curr*49 + prev2] = dg[prev2*49 + curr] = v;
+		}
+		for(int k = bA;k <= bI;++k) for(int l = bA;l <= bI;++l){
+			const int prev = k*NB + l;
+			if(!PCR_WC[curr] && !PCR_WC[prev]) dg[curr*49 + prev] = std::max(0, scale(PCR_SUPP[0] - TARGET_T*(PCR_SUPP[1] + loop_sc)));
+		}
+	}
+	for(int i = bA;i <= bI;++i) for(int j = bA;j <= bI;++j){
+		const int v = std::max(0, scale(PCR_SUPP[2] - TARGET_T*(PCR_SUPP[3] + bulge_sc)));
+		dg[(i*NB + bGAP)*49 + (j*NB + bGAP)] = v;
+		dg[(bGAP*NB + i)*49 + (bGAP*NB + j)] = v;
+	}
+}
+
+bool job_set(unsigned char *dst, unsigned char &len, const std::vector<uint8_t> &s)
+{
+	if(s.empty() || s.size() > (size_t)thermo::MAXL) return false;
+	for(size_t i = 0;i < s.size();++i){ if(s[i] > 3) return false; dst[i] = s[i]; }
+	len = (unsigned char)s.size();
+	return true;
+}
+
+int run_thermo_jobs(pcr_ctx *ctx, const std::vector<thermo::Job> &jobs, float salt, std::vector<thermo::JobOut> &out)
+{
+	out.resize(jobs.size());
+	if(jobs.empty()) return PCR_OK;
+	if(!(salt >= 1.0e-6f && salt <= 1.0f)){ g_err = "thermo: salt outside [1e-6, 1] (NucCruc::salt, nuc_cruc.h:780-788)"; return PCR_ERR_ARG; }
+	int dg[49*49];
+	build_dg_table(salt, dg);
+	const size_t n = jobs.size();
+	const size_t n_blocks = (n + thermo::THERMO_THREADS - 1)/thermo::THERMO_THREADS;
+	// bound the scratch slab: run the jobs in chunks of <= 4096 blocks (~3.4 GB of DP matrices)
+	const size_t max_blocks = 4096;
+	int rc;
+	if((rc = ctx->th_dg.ensure(49*49)) != PCR_OK) return rc;
+	if((rc = ctx->th_jobs.ensure(n)) != PCR_OK) return rc;
+	if((rc = ctx->th_out.ensure(n)) != PCR_OK) return rc;
+	const size_t blk = std::min(n_blocks, max_blocks);
+	if((rc = ctx->th_scratch_i.ensure(blk*3*thermo::NCELL*thermo::WAVE)) != PCR_OK) return rc;
+	if((rc = ctx->th_scratch_s.ensure(blk*thermo::NCELL*thermo::WAVE)) != PCR_OK) return rc;
+	HIP_TRY(hipMemcpyAsync(ctx->th_dg.p, dg, sizeof(dg), hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(hipMemcpyAsync(ctx->th_jobs.p, jobs.data(), n*sizeof(thermo::Job), hipMemcpyHostToDevice, ctx->stream));
+	const float log_na = logf(salt);
+	for(size_t b0 = 0;b0 < n_blocks;b0 += max_blocks){
+		const size_t nb = std::min(max_blocks, n_blocks - b0);
+		const size_t j0 = b0*thermo::THERMO_THREADS;
+		const unsigned nj = (unsigned)std::min<size_t>(n - j0, nb*thermo::THERMO_THREADS);
+		hipLaunchKernelGGL(thermo::k_thermo, dim3((unsigned)nb), dim3(thermo::THERMO_THREADS), 0, ctx->stream, ctx->th_jobs.p + j0, nj,
+			ctx->th_dg.p, log_na, ctx->th_scratch_i.p, ctx->th_scratch_s.p, ctx->th_out.p + j0);
+		HIP_TRY(hipGetLastError());
+	}
+	HIP_TRY(hipMemcpyAsync(out.data(), ctx->th_out.p, n*sizeof(thermo::JobOut), hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	for(size_t i = 0;i < n;++i){ if(out[i].status & 1u){ g_err = "thermo: internal trace-back error"; return PCR_ERR_RANGE; } }
+	return PCR_OK;
+}
+
+const size_t MAX_EXPANSIONS = 1u << 16;
+
+} // namespace
+
+extern "C" {
+
+int pcr_thermo(pcr_ctx *ctx, const pcr_word128 *oligos, uint32_t n, int check_homo_dimer, const pcr_thermo_args *args,
+	pcr_thermo_result *out)
+{
+	if(!ctx || !args || (n && (!oligos || !out))){ g_err = "pcr_thermo: bad argument"; return PCR_ERR_ARG; }
+	HIP_TRY(hipSetDevice(ctx->device));
+	std::vector<thermo::Job> jobs;
+	std::vector<uint32_t> first(n + 1, 0);
+	for(uint32_t i = 0;i < n;++i){
+		first[i] = (uint32_t)jobs.size();
+		const Planes w = pcrhost::planes_of_word(oligos[i].w);
+		std::vector<std::vector<uint8_t> > ex;
+		if(!pcrhost::expand_oligo(w, ex, MAX_EXPANSIONS)){ g_err = "pcr_thermo: more than 65536 expansions of one oligo"; return PCR_ERR_CAPACITY; }
+		if(ex.empty()){ g_err = "pcr_thermo: empty oligo"; return PCR_ERR_ARG; }
+		const double degen = pcrhost::planes_degeneracy(w);
+		const float strand = (float)(args->primer_strand/degen);                 // valid_pcr.cpp:13
+		for(const std::vector<uint8_t> &s : ex){
+			thermo::Job j; memset(&j, 0, sizeof(j));
+			if(!job_set(j.q, j.qlen, s)){ g_err = "pcr_thermo: oligo is empty, longer than 32 or holds a non-base slot (NucCruc::set_query throws)"; return PCR_ERR_ARG; }
+			j.mode = 0; j.check_homo = check_homo_dimer ? 1 : 0; j.log_strand = logf(strand);
+			jobs.push_back(j);
+		}
+	}
+	first[n] = (uint32_t)jobs.size();
+	std::vector<thermo::JobOut> res;
+	int rc = run_thermo_jobs(ctx, jobs, args->salt, res);
+	if(rc != PCR_OK) return rc;
+	for(uint32_t i = 0;i < n;++i){
+		pcr_thermo_result r; memset(&r, 0, sizeof(r));
+		r.n_expansions = first[i + 1] - first[i];
+		r.valid = 1;
+		for(uint32_t k = first[i];k < first[i + 1];++k){
+			const thermo::JobOut &o = res[k];
+			if(o.tm_pm < args->tm_min || o.tm_pm > args->tm_max) r.valid = 0;     // valid_pcr.cpp:19-23
+			if(o.tm_hairpin > args->max_hairpin) r.valid = 0;                     // :27-31
+			if(check_homo_dimer && o.tm_dimer > args->max_dimer) r.valid = 0;     // :34-41
+		}
+		if(r.n_expansions){
+			const thermo::JobOut &o = res[first[i]];
+			r.tm = o.tm_pm; r.dH = o.dH_pm; r.dS = o.dS_pm; r.hairpin_tm = o.tm_hairpin; r.homodimer_tm = o.tm_dimer;
+		}
+		out[i] = r;
+	}
+	return PCR_OK;
+}
+
+int pcr_dimer(pcr_ctx *ctx, const pcr_pair *pairs, uint32_t n, const pcr_thermo_args *args, float *max_tm)
+{
+	if(!ctx || !args || (n && (!pairs || !max_tm))){ g_err = "pcr_dimer: bad argument"; return PCR_ERR_ARG; }
+	HIP_TRY(hipSetDevice(ctx->device));
+	std::vector<thermo::Job> jobs;
+	std::vector<uint32_t> first(n + 1, 0);
+	for(uint32_t i = 0;i < n;++i){
+		first[i] = (uint32_t)jobs.size();
+		const Planes F = pcrhost::planes_of_word(pairs[i].f.w), R = pcrhost::planes_of_word(pairs[i].r.w);
+		std::vector<std::vector<uint8_t> > ef, er;
+		if(!pcrhost::expand_oligo(F, ef, MAX_EXPANSIONS) || !pcrhost::expand_oligo(R, er, MAX_EXPANSIONS) || ef.size()*er.size() > MAX_EXPANSIONS){
+			g_err = "pcr_dimer: too many expansions"; return PCR_ERR_CAPACITY;
+		}
+		const float ca = (float)(args->primer_strand/pcrhost::planes_degeneracy(F));   // pcr_assay.cpp:244
+		const float cb = (float)(args->primer_strand/pcrhost::planes_degeneracy(R));
+		const float strand = (ca > cb) ? ca - 0.5f*cb : cb - 0.5f*ca;             // nuc_cruc.h:832-837
+		for(const std::vector<uint8_t> &f : ef) for(const std::vector<uint8_t> &r : er){
+			thermo::Job j; memset(&j, 0, sizeof(j));
+			if(!job_set(j.q, j.qlen, f) || !job_set(j.t, j.tlen, r)){ g_err = "pcr_dimer: bad oligo"; return PCR_ERR_ARG; }
+			j.mode = 1; j.log_strand = logf(strand);
+			jobs.push_back(j);
+		}
+	}
+	first[n] = (uint32_t)jobs.size();
+	std::vector<thermo::JobOut> res;
+	int rc = run_thermo_jobs(ctx, jobs, args->salt, res);
+	if(rc != PCR_OK) return rc;
+	for(uint32_t i = 0;i < n;++i){
+		float m = 0.0f;
+		for(uint32_t k = first[i];k < first[i + 1];++k) m = std::max(m, res[k].tm_dimer);   // :262
+		max_tm[i] = m;
+	}
+	return PCR_OK;
+}
+
+int pcr_multiplex_compatible(pcr_ctx *ctx, const pcr_pair *a, const pcr_pair *b, uint32_t n, const pcr_thermo_args *args, uint8_t *ok)
+{
+	if(!ctx || !args || (n && (!a || !b || !ok))){ g_err = "pcr_multiplex_compatible: bad argument"; return PCR_ERR_ARG; }
+	HIP_TRY(hipSetDevice(ctx->device));
+	std::vector<thermo::Job> jobs;
+	std::vector<uint32_t> first(n + 1, 0);
+	const float log_strand = logf(args->primer_strand);                          // pcr_assay.cpp:819-821
+	for(uint32_t i = 0;i < n;++i){
+		first[i] = (uint32_t)jobs.size();
+		const uint64_t *qa[2] = {a[i].f.w, a[i].r.w}, *sb[2] = {b[i].f.w, b[i].r.w};
+		for(int qo = 0;qo < 2;++qo){
+			std::vector<std::vector<uint8_t> > eq;
+			if(!pcrhost::expand_oligo(pcrhost::planes_of_word(qa[qo]), eq, MAX_EXPANSIONS)){ g_err = "too many expansions"; return PCR_ERR_CAPACITY; }
+			for(int so = 0;so < 2;++so){
+				std::vector<std::vector<uint8_t> > es;
+				if(!pcrhost::expand_oligo(pcrhost::planes_of_word(sb[so]), es, MAX_EXPANSIONS) || eq.size()*es.size() > MAX_EXPANSIONS){
+					g_err = "too many expansions"; return PCR_ERR_CAPACITY;
+				}
+				for(const std::vector<uint8_t> &q : eq) for(const std::vector<uint8_t> &s : es){
+					thermo::Job j; memset(&j, 0, sizeof(j));
+					if(!job_set(j.q, j.qlen, q) || !job_set(j.t, j.tlen, s)){ g_err = "pcr_multiplex_compatible: bad oligo"; return PCR_ERR_ARG; }
+					j.mode = 1; j.log_strand = log_strand;
+					jobs.push_back(j);
+				}
+			}
+		}
+	}
+	first[n] = (uint32_t)jobs.size();
+	std::vector<thermo::JobOut> res;
+	int rc = run_thermo_jobs(ctx, jobs, args->salt, res);
+	if(rc != PCR_OK) return rc;
+	for(uint32_t i = 0;i < n;++i){
+		uint8_t good = 1;
+		for(uint32_t k = first[i];k < first[i + 1];++k){ if(res[k].tm_dimer >= args->max_dimer) good = 0; }   // :841
+		ok[i] = good;
+	}
 	return PCR_OK;
 }
 

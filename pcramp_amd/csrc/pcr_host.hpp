@@ -407,5 +407,53 @@ inline void build_candidates(const uint64_t *pairs /* n x {F[2],R[2]} */, uint32
 	}
 }
 
+// ---------------------------------------------------------------------------------------------
+// IUPAC expansion of an oligo in the order of Word::begin()/next() (word.h:525-647): an odometer
+// whose fastest digit is slot 15, then 14 ... 0, then 31 ... 16 (the reference walks its two
+// 64-bit blocks from the least significant nibble up); within a slot A -> C -> G -> T restricted
+// to the slot's base set.  Each expansion is returned as base indices 0..3 (A,C,G,T) of the
+// occupied slots start()..stop(), i.e. what Word::str() spells.
+inline bool expand_oligo(const Planes &w, std::vector<std::vector<uint8_t> > &out, size_t cap)
+{
+	int order[32];
+	for(int i = 0;i < 16;++i){ order[i] = 15 - i; order[16 + i] = 31 - i; }
+	uint8_t set[32], cur[32];
+	for(int k = 0;k < 32;++k){ set[k] = (uint8_t)planes_nibble(w, k); cur[k] = set[k] ? (uint8_t)(set[k] & (0u - set[k])) : 0; }
+	const int first = planes_start(w), last = planes_stop(w);
+	if(last < first) return true;
+	while(true){
+		if(out.size() >= cap) return false;
+		std::vector<uint8_t> s;
+		for(int k = first;k <= last;++k){
+			const uint8_t c = cur[k];
+			s.push_back((c == 1) ? 0 : (c == 2) ? 1 : (c == 4) ? 2 : (c == 8) ? 3 : 255);   // EOS inside an oligo: illegal base
+		}
+		out.push_back(s);
+		bool advanced = false;
+		for(int oi = 0;oi < 32 && !advanced;++oi){
+			const int k = order[oi];
+			if(cur[k] == 0) continue;
+			bool wrapped = false;
+			unsigned c = cur[k];
+			do{
+				if(c == 8){ c = 1; wrapped = true; }
+				else c <<= 1;
+			} while(!(c & set[k]));
+			cur[k] = (uint8_t)c;
+			if(!wrapped) advanced = true;
+		}
+		if(!advanced) break;
+	}
+	return true;
+}
+
+// Word::degeneracy() (word.h:97-138): product of the slot multiplicities, in double
+inline double planes_degeneracy(const Planes &w)
+{
+	double r = 1.0;
+	for(int k = 0;k < 32;++k){ const int d = __builtin_popcount(planes_nibble(w, k)); if(d) r *= d; }
+	return r;
+}
+
 } // namespace pcrhost
 #endif
