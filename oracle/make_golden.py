@@ -113,11 +113,99 @@ def screen_golden(ref):
     return {"cases": cases}
 
 
+def sw_golden(ref):
+    """8-lane SeqOverlap calls (seq_overlap.cpp:347) on word pairs; lanes with score 0 keep only the score."""
+    rng = random.Random(404)
+    from testdata import mutate
+    cases = []
+    for it in range(40):
+        qs, ts = [], []
+        for lane in range(8):
+            qtxt = rand_seq(rng, rng.randint(6, 32), p_degen=0.05)
+            m = rng.random()
+            if m < 0.55:
+                core = mutate(rng, qtxt, 0.12)
+                if rng.random() < 0.4 and len(core) > 6:
+                    k = rng.randrange(2, len(core) - 2)
+                    core = core[:k] + (rand_seq(rng, 1) if rng.random() < 0.5 else "") + core[k + (rng.random() < 0.5):]
+                core = core[:32]
+                left = rng.randint(0, 32 - len(core))
+                ttxt = (rand_seq(rng, left) + core + rand_seq(rng, 32))[:rng.randint(min(32, left + len(core)), 32)]
+            elif m < 0.65:
+                qtxt, ttxt = "A" * rng.randint(10, 20), "A" * rng.randint(10, 32)
+            else:
+                ttxt = rand_seq(rng, rng.randint(6, 32), p_degen=0.05)
+            q, t = ref.word(qtxt), ref.word(ttxt)
+            for _ in range(rng.randint(0, 32 - len(qtxt))):
+                q = ref.word_shift_right(q)
+            for _ in range(rng.randint(0, 32 - len(ttxt))):
+                t = ref.word_shift_right(t)
+            qs.append(q); ts.append(t)
+        res = ref.sw_align_words8(qs, ts)
+        for lane in range(8):
+            r = res[lane]
+            cases.append({"q": hexw(qs[lane]), "t": hexw(ts[lane]), "score": r[0],
+                          "rest": list(r[1:]) if r[0] > 0 else None})
+    return {"cases": cases}
+
+
+def thermo_golden(ref):
+    """NucCruc values (deterministic harness form, see ref_harness.cpp: rings pre-filled with E)."""
+    rng = random.Random(505)
+    from testdata import mutate
+    oligos = []
+    for it in range(400):
+        n = rng.randint(12, 32)
+        m = rng.random()
+        if m < 0.6:
+            s = rand_seq(rng, n)
+        elif m < 0.8:
+            stem = rand_seq(rng, rng.randint(4, 8))
+            s = (rand_seq(rng, rng.randint(0, 4)) + stem + rand_seq(rng, rng.randint(3, 7)) + mutate(rng, revcomp(stem), 0.1) + rand_seq(rng, 8))[:32]
+            if len(s) < 12:
+                s += rand_seq(rng, 12)
+        else:
+            s = (rand_seq(rng, rng.randint(1, 4)) * 32)[:n]
+        salt = rng.choice([0.05, 0.05, 0.01, 0.2])
+        strand = rng.choice([9e-7, 9e-7, 4.5e-7, 2e-8])
+        oligos.append({"seq": s, "salt": salt, "strand": strand, "out": [float(x) for x in ref.thermo_full(s, salt, strand)]})
+    hetero = []
+    for it in range(200):
+        a = rand_seq(rng, rng.randint(12, 30))
+        if rng.random() < 0.5:
+            b = rand_seq(rng, rng.randint(12, 30))
+        else:
+            core = mutate(rng, revcomp(a[rng.randint(0, 5):rng.randint(len(a) - 5, len(a))]), 0.15)
+            b = (rand_seq(rng, rng.randint(0, 4)) + core + rand_seq(rng, rng.randint(0, 4)))[:32]
+        sa, sb = rng.choice([(9e-7, 9e-7), (9e-7, 4.5e-7), (1e-7, 9e-7)])
+        hetero.append({"a": a, "b": b, "sa": sa, "sb": sb, "out": [float(x) for x in ref.heterodimer_full(a, b, 0.05, sa, sb)]})
+    filt = []
+    for it in range(120):
+        w = ref.centered_word(rand_seq(rng, rng.randint(18, 25), p_degen=0.06 if it % 3 == 0 else 0.0))
+        if ref.word_degeneracy(w) > 16:
+            continue
+        kw = dict(tm_min=rng.choice([45.0, 50.0]), tm_max=rng.choice([65.0, 75.0]), max_hairpin=rng.choice([30.0, 40.0]),
+                  max_dimer=rng.choice([30.0, 40.0]), check_homo_dimer=bool(it & 1))
+        filt.append({"word": hexw(w), "kw": kw, "valid": ref.is_valid(w, **kw)})
+    dimers = []
+    for it in range(60):
+        f = ref.centered_word(rand_seq(rng, rng.randint(18, 25), p_degen=0.04))
+        r = ref.centered_word(rand_seq(rng, rng.randint(18, 25), p_degen=0.04))
+        if ref.word_degeneracy(f) * ref.word_degeneracy(r) > 64:
+            continue
+        f2 = ref.centered_word(rand_seq(rng, rng.randint(18, 25)))
+        r2 = ref.centered_word(revcomp(rand_seq(rng, 6) + "ACGTTGCAAT" + rand_seq(rng, 5)))
+        dimers.append({"pair": hexw(f) + hexw(r), "max_dimer_tm": float(ref.max_dimer_tm((f, r))), "other": hexw(f2) + hexw(r2),
+                       "compatible": {str(md): ref.multiplex_compatible((f, r), (f2, r2), max_dimer=md) for md in (10.0, 25.0, 40.0)}})
+    return {"oligos": oligos, "hetero": hetero, "is_valid": filt, "dimers": dimers}
+
+
 def main():
     build_reference()
     ref = Reference()
     os.makedirs(OUT, exist_ok=True)
-    for name, fn in (("words", words_golden), ("pack", pack_golden), ("screen", screen_golden)):
+    for name, fn in (("words", words_golden), ("pack", pack_golden), ("screen", screen_golden), ("sw", sw_golden),
+                     ("thermo", thermo_golden)):
         with open(os.path.join(OUT, name + ".json"), "w") as f:
             json.dump(fn(ref), f, separators=(",", ":"))
         print("wrote", name, os.path.getsize(os.path.join(OUT, name + ".json")), "bytes")

@@ -36,3 +36,49 @@ def test_screen_golden(ci):
         assert bits[k].astype(int).tolist() == c["bits"][k]
         assert cov[k] == np.float32(c["coverage"][k])
     d.close()
+
+
+def _w(h):
+    return (int(h[0], 16), int(h[1], 16))
+
+
+def test_sw_golden():
+    with open(os.path.join(G, "sw.json")) as f:
+        cases = json.load(f)["cases"]
+    d = api.Screener(0)
+    got = d.sw_align_words([_w(c["q"]) for c in cases], [_w(c["t"]) for c in cases])
+    for c, r in zip(cases, got):
+        assert r[0] == c["score"]
+        if c["rest"] is not None:
+            assert list(r[1:7]) == c["rest"]
+    d.close()
+
+
+def test_thermo_golden():
+    with open(os.path.join(G, "thermo.json")) as f:
+        g = json.load(f)
+    d = api.Screener(0)
+    from pcramp_amd import words as W
+    by = {}
+    for c in g["oligos"]:
+        by.setdefault((c["salt"], c["strand"]), []).append(c)
+    for (salt, strand), cs in by.items():
+        res = d.is_valid([W.centered_word(W.codes_from_text(c["seq"])) for c in cs], True, salt=salt, primer_strand=strand)
+        for c, r in zip(cs, res):
+            o = np.array(c["out"], np.float32)
+            for got, want in ((r["tm"], o[0]), (r["dH"], o[1]), (r["dS"], o[2]), (r["hairpin_tm"], o[4]), (r["homodimer_tm"], o[7])):
+                assert abs(float(got) - float(want)) <= 1e-6 * max(1.0, abs(float(want))), c["seq"]
+    for c in g["is_valid"]:
+        kw = dict(c["kw"])
+        chk = kw.pop("check_homo_dimer")
+        assert int(d.is_valid([_w(c["word"])], chk, **kw)[0]["valid"]) == c["valid"]
+    pairs = [(_w(c["pair"][:2]), _w(c["pair"][2:])) for c in g["dimers"]]
+    others = [(_w(c["other"][:2]), _w(c["other"][2:])) for c in g["dimers"]]
+    tm = d.max_dimer_tm(pairs)
+    for c, t in zip(g["dimers"], tm):
+        assert abs(float(t) - c["max_dimer_tm"]) <= 1e-6 * max(1.0, abs(c["max_dimer_tm"]))
+    for md in ("10.0", "25.0", "40.0"):
+        ok = d.multiplex_compatible(pairs, others, max_dimer=float(md))
+        for c, o in zip(g["dimers"], ok):
+            assert int(o) == c["compatible"][md]
+    d.close()

@@ -63,3 +63,29 @@ def test_screen(oracle, ci):
     for k, p in enumerate(pairs):
         assert s.target_match(p).tolist() == c["bits"][k]
         assert s.target_coverage(p) == np.float32(c["coverage"][k])
+
+
+def test_sw(oracle):
+    for c in load("sw")["cases"]:
+        r = oracle.sw_align_words(w(c["q"]), w(c["t"]))
+        assert r.score == c["score"]
+        if c["rest"] is not None:
+            assert list(r.tup()[1:]) == c["rest"]
+
+
+def test_thermo(oracle):
+    g = load("thermo")
+    for c in g["oligos"]:
+        o = oracle.thermo_full(c["seq"], c["salt"], c["strand"])
+        assert (o == np.array(c["out"], np.float32)).all(), c["seq"]
+    for c in g["hetero"]:
+        o = oracle.heterodimer_full(c["a"], c["b"], 0.05, c["sa"], c["sb"])
+        assert (o == np.array(c["out"], np.float32)).all()
+    for c in g["is_valid"]:
+        assert oracle.is_valid(w(c["word"]), **c["kw"]) == c["valid"]
+    for c in g["dimers"]:
+        p = (w(c["pair"][:2]), w(c["pair"][2:]))
+        q = (w(c["other"][:2]), w(c["other"][2:]))
+        assert oracle.max_dimer_tm(p) == np.float32(c["max_dimer_tm"])
+        for md, v in c["compatible"].items():
+            assert oracle.multiplex_compatible(p, q, max_dimer=float(md)) == v
