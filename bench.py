@@ -119,7 +119,7 @@ def main():
     gathered = torch.zeros((world, 2, P, words), dtype=torch.int64, device=dev_t) if world > 1 else None
 
     def step():
-        scr.select_words(pa, select_thr, 18)
+        scr.select_words(pa, select_thr, 18, count=False)
         scr.amplify_device(pa, local[0].data_ptr(), local[1].data_ptr(), thr_t, thr_t, 80, 200, False)
         if world > 1:
             dist.all_gather_into_tensor(gathered.view(-1), local.view(-1))

@@ -256,12 +256,14 @@ class Screener:
     def split(self, seq, pos, which=TARGET):
         self._check(self.L.pcr_split(self.h, which, seq, pos))
 
-    def select_words(self, pairs, threshold, min_oligo_length=18, optimize_5=False, optimize_3=False, which=TARGET):
+    def select_words(self, pairs, threshold, min_oligo_length=18, optimize_5=False, optimize_3=False, which=TARGET,
+                     count=True):
+        """count=False skips the (host-side) DB size computation and returns None."""
         a = pairs if isinstance(pairs, np.ndarray) else W.pairs_array(pairs)
         n = C.c_uint64(0)
         self._check(self.L.pcr_select_words(self.h, which, a.ctypes.data, a.shape[0], int(optimize_5), int(optimize_3),
-                                            threshold, min_oligo_length, C.byref(n)))
-        return n.value
+                                            threshold, min_oligo_length, C.byref(n) if count else None))
+        return n.value if count else None
 
     def entries(self, which=TARGET):
         n = self.L.pcr_get_entries(self.h, which, None, 0)

@@ -14,11 +14,11 @@
 //   k_transpose, k_valid  : load-time index build (replaces Sequence::operator= + the filter half of pack)
 //   k_scan, k_scan_irr    : oligo x window match counts + per-(sequence,candidate) running max
 //                           (select_words.cpp:88-117 over the implicit word index)
-//   k_filter, k_entries   : arg-max-with-ties selection -> the device word DB (select_words.cpp:126-138)
+//   k_finalize            : per-sequence arg-max-with-ties filter, sort, dedupe -> the device word DB
+//                           (select_words.cpp:100-138)
 //   k_match, k_pair       : match_words / find_oligo_match / find_amplicon_match / update_identity /
 //                           sqrtf(f*r) test (optimize.cpp:209-301, pcr_assay.cpp:12-69,338-441,544-578)
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 
 #include <stdint.h>
 #include <string.h>
@@ -186,17 +186,25 @@ __global__ void k_valid(const uint4 *__restrict__ planes, const uint64_t *__rest
 }
 
 // ============================================================================== select_words
-__device__ __noinline__ void record_hit(uint32_t *__restrict__ best, Hit *__restrict__ hits,
-	uint32_t *__restrict__ counters, uint32_t hit_cap, uint32_t ncand,
-	uint32_t seq, uint32_t cand, uint64_t key, uint32_t cnt)
+// Hits are appended to a fixed-capacity bucket per sequence (`cap` slots each), so the arg-max
+// filter, the dedupe and the ordering by WordMatch::loc can be done per sequence by one workgroup
+// (k_finalize) with no global sort.  counters[0]: overflow flag, counters[2]: largest bucket fill seen.
+struct HitSink { uint32_t *best; Hit *hits; uint32_t *seq_count; uint32_t *counters; uint32_t *touched; uint32_t cap; uint32_t ncand; uint32_t epoch; };
+// counters[3] / touched[]: the sequences that received at least one hit, in arrival order.
+// best[] holds (pass epoch << 8) | count, so it never needs clearing: values of earlier passes compare lower.
+
+__device__ __noinline__ void record_hit(const HitSink &k, uint32_t seq, uint32_t cand, uint64_t key, uint32_t cnt)
 {
-	const uint32_t old = atomicMax(&best[(size_t)seq*ncand + cand], cnt);
-	if(cnt >= old){
-		const uint32_t idx = atomicAdd(&counters[0], 1u);
-		if(idx < hit_cap){
+	const uint32_t tagged = (k.epoch << 8) | cnt;
+	const uint32_t old = atomicMax(&k.best[(size_t)seq*k.ncand + cand], tagged);
+	if(tagged >= old){
+		const uint32_t slot = atomicAdd(&k.seq_count[seq], 1u);
+		if(slot == 0) k.touched[atomicAdd(&k.counters[3], 1u)] = seq;
+		if(slot < k.cap){
 			Hit h; h.key = key; h.cand = cand; h.cnt = cnt;
-			hits[idx] = h;
+			k.hits[(size_t)seq*k.cap + slot] = h;
 		}
+		else{ atomicOr(&k.counters[0], 1u); atomicMax(&k.counters[2], slot + 1); }
 	}
 }
 
@@ -213,7 +221,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(
 	const uint64_t *__restrict__ blk_off, const uint64_t *__restrict__ len, const uint8_t *__restrict__ active,
 	const uint32_t *__restrict__ tile_seq, const uint32_t *__restrict__ tile_pos0,
 	const uint4 *__restrict__ cand_fwd, const uint4 *__restrict__ cand_rc, const uint32_t *__restrict__ cand_floor,
-	uint32_t ncand, uint32_t *__restrict__ best, Hit *__restrict__ hits, uint32_t *__restrict__ counters, uint32_t hit_cap)
+	uint32_t ncand, HitSink sink)
 {
 	const uint32_t tile = blockIdx.x;
 	const uint32_t seq = tile_seq[tile];
@@ -247,61 +255,56 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(
 			const uint32_t cr = match_count(wa[i], wc[i], wg[i], wt[i], mr);
 			if((cf >= fl || cr >= fl) && ok[i]){
 				const int32_t p = (int32_t)(p0 + threadIdx.x + SCAN_THREADS*i);
-				if(cf >= fl) record_hit(best, hits, counters, hit_cap, ncand, seq, c, make_key(seq, p, 1, 0, 0), cf);       // sequence.cpp:184
-				if(cr >= fl) record_hit(best, hits, counters, hit_cap, ncand, seq, c, make_key(seq, p + 31, 2, 0, 0), cr);  // sequence.cpp:190
+				if(cf >= fl) record_hit(sink, seq, c, make_key(seq, p, 1, 0, 0), cf);       // sequence.cpp:184
+				if(cr >= fl) record_hit(sink, seq, c, make_key(seq, p + 31, 2, 0, 0), cr);  // sequence.cpp:190
 			}
 		}
 	}
 }
 
-// Irregular words: one lane per word, candidates uniform.
-__global__ void k_scan_irr(const IrrDev *__restrict__ irr, uint32_t n_irr, const uint8_t *__restrict__ active,
+// Irregular words: one lane per word; the candidate masks are staged through LDS in chunks.
+constexpr int IRR_THREADS = 256, IRR_CHUNK = 512;
+__global__ __launch_bounds__(IRR_THREADS) void k_scan_irr(const IrrDev *__restrict__ irr, uint32_t n_irr, const uint8_t *__restrict__ active,
 	uint32_t min_len, const uint4 *__restrict__ cand_fwd, const uint32_t *__restrict__ cand_floor, uint32_t ncand,
-	uint32_t *__restrict__ best, Hit *__restrict__ hits, uint32_t *__restrict__ counters, uint32_t hit_cap)
+	HitSink sink)
 {
-	const uint32_t i = blockIdx.x*blockDim.x + threadIdx.x;
-	if(i >= n_irr) return;
-	const IrrDev e = irr[i];
-	if(!active[e.seq]) return;
-	const uint32_t cws = (e.meta >> 8) & 0xFF;
-	if(cws < min_len) return;                                                    // sequence.cpp:157,239
-	const uint32_t strand = e.meta & 0xFF, ord = (e.meta >> 16) & 0xFF;
-	const uint64_t key = make_key(e.seq, e.loc, strand, 1, ord);
-	for(uint32_t c = 0;c < ncand;++c){
-		const uint32_t cnt = match_count(e.w.a, e.w.c, e.w.g, e.w.t, cand_fwd[c]);
-		if(cnt >= cand_floor[c]) record_hit(best, hits, counters, hit_cap, ncand, e.seq, c, key, cnt);
+	__shared__ uint4 c_m[IRR_CHUNK];
+	__shared__ uint32_t c_f[IRR_CHUNK];
+	for(uint32_t c0 = 0;c0 < ncand;c0 += IRR_CHUNK){
+		const uint32_t nc = min((uint32_t)IRR_CHUNK, ncand - c0);
+		__syncthreads();
+		for(uint32_t c = threadIdx.x;c < nc;c += IRR_THREADS){ c_m[c] = cand_fwd[c0 + c]; c_f[c] = cand_floor[c0 + c]; }
+		__syncthreads();
+		for(uint32_t i = blockIdx.x*IRR_THREADS + threadIdx.x;i < n_irr;i += gridDim.x*IRR_THREADS){
+			const IrrDev e = irr[i];
+			if(!active[e.seq] || (((e.meta >> 8) & 0xFF) < min_len)) continue;           // sequence.cpp:157,239
+			const uint64_t key = make_key(e.seq, e.loc, e.meta & 0xFF, 1, (e.meta >> 16) & 0xFF);
+			for(uint32_t c = 0;c < nc;++c){
+				const uint32_t cnt = match_count(e.w.a, e.w.c, e.w.g, e.w.t, c_m[c]);
+				if(cnt >= c_f[c]) record_hit(sink, e.seq, c0 + c, key, cnt);
+			}
+		}
 	}
 }
 
 #include "pcr_scan_bitsliced.inc"
 
-// Keep the hits that attain the final per-(sequence,candidate) maximum (select_words.cpp:100-117).
-__global__ void k_filter(const Hit *__restrict__ hits, uint32_t n_hits, const uint32_t *__restrict__ best,
-	uint32_t ncand, uint64_t *__restrict__ keys, uint32_t *__restrict__ counters)
-{
-	const uint32_t i = blockIdx.x*blockDim.x + threadIdx.x;
-	if(i >= n_hits) return;
-	const Hit h = hits[i];
-	const uint32_t seq = (uint32_t)(h.key >> KEY_SEQ_SHIFT);
-	if(h.cnt == best[(size_t)seq*ncand + h.cand]){
-		const uint32_t k = atomicAdd(&counters[1], 1u);
-		keys[k] = h.key;   // capacity == hit capacity >= n_hits
-	}
-}
+// One workgroup per sequence: keep the hits that attain the final per-(sequence,candidate) maximum
+// (select_words.cpp:100-117), sort them by (loc, strand, kind, ord) (bitonic, LDS), drop duplicates
+// (the union over candidates, select_words.cpp:126-128) and materialise the DB entries of the
+// sequence into its slot range [seq*cap, seq*cap + n).  seg_hi[seq] = seq*cap + n.
+constexpr int FIN_WAVES = 8, FIN_THREADS = 64*FIN_WAVES;   // one wave per sequence, 8 sequences per workgroup
 
-// Sorted unique keys -> materialised DB entries + per-sequence segments.
-__global__ void k_entries(const uint64_t *__restrict__ keys, uint32_t n, const uint4 *__restrict__ planes,
-	const uint64_t *__restrict__ blk_off, const IrrDev *__restrict__ irr, const uint32_t *__restrict__ irr_off,
-	DevEntry *__restrict__ out, uint32_t *__restrict__ seg_lo, uint32_t *__restrict__ seg_hi)
+// LDS hand-off between lanes of ONE wave: order the wave's own LDS traffic, no workgroup barrier
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
+__device__ void materialise_entry(uint64_t k, const uint4 *__restrict__ planes, const uint64_t *__restrict__ blk_off,
+	const IrrDev *__restrict__ irr, const uint32_t *__restrict__ irr_off, DevEntry &e)
 {
-	const uint32_t i = blockIdx.x*blockDim.x + threadIdx.x;
-	if(i >= n) return;
-	const uint64_t k = keys[i];
 	const uint32_t seq = (uint32_t)(k >> KEY_SEQ_SHIFT);
 	const int32_t loc = (int32_t)(uint32_t)((k >> KEY_LOC_SHIFT) & 0xFFFFFFFFull) - LOC_BIAS;
 	const uint32_t strand = (uint32_t)((k >> 7) & 1) + 1;
 	const uint32_t kind = (uint32_t)((k >> 6) & 1), ord = (uint32_t)(k & 63);
-	DevEntry e;
 	e.loc = loc; e.seq = seq; e.strand = strand; e.pad = 0;
 	if(kind == 0){
 		const uint32_t p = (strand == 1) ? (uint32_t)loc : (uint32_t)(loc - 31);
@@ -314,26 +317,103 @@ __global__ void k_entries(const uint64_t *__restrict__ keys, uint32_t n, const u
 		else{ e.w.a = __brev(t); e.w.t = __brev(a); e.w.c = __brev(g); e.w.g = __brev(c); }   // Word::complement, word.h:140
 	}
 	else{
-		// find the irregular word with this (loc, strand, ord) in the sequence's list
+		// the irregular word with this (loc, strand, ord) in the sequence's list
 		e.w.a = e.w.c = e.w.g = e.w.t = 0;
 		for(uint32_t j = irr_off[seq];j < irr_off[seq + 1];++j){
 			const IrrDev r = irr[j];
 			if(r.loc == loc && (r.meta & 0xFF) == strand && ((r.meta >> 16) & 0xFF) == ord){ e.w = r.w; break; }
 		}
 	}
-	out[i] = e;
-	if(i == 0 || (uint32_t)(keys[i - 1] >> KEY_SEQ_SHIFT) != seq) seg_lo[seq] = i;
-	if(i == n - 1 || (uint32_t)(keys[i + 1] >> KEY_SEQ_SHIFT) != seq) seg_hi[seq] = i + 1;
+}
+
+__global__ __launch_bounds__(FIN_THREADS) void k_finalize(const Hit *__restrict__ hits, const uint32_t *__restrict__ seq_count,
+	uint32_t cap, const uint32_t *__restrict__ best, uint32_t ncand, const uint4 *__restrict__ planes,
+	const uint64_t *__restrict__ blk_off, const IrrDev *__restrict__ irr, const uint32_t *__restrict__ irr_off,
+	DevEntry *__restrict__ db, uint32_t *__restrict__ seg_hi, uint32_t *__restrict__ counters, uint32_t epoch,
+	const uint32_t *__restrict__ touched)
+{
+	extern __shared__ __attribute__((aligned(16))) uint64_t fin_lds[];   // FIN_WAVES x np2cap keys
+	__shared__ uint32_t part_all[FIN_THREADS];
+	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const uint32_t t_idx = blockIdx.x*FIN_WAVES + wave;
+	if(t_idx >= counters[3]) return;            // only sequences that received hits (seg_hi of the others stays 0 = empty)
+	const uint32_t seq = touched[t_idx];
+	uint32_t np2cap = 1; while(np2cap < cap) np2cap <<= 1;
+	uint64_t *fin_keys = fin_lds + (size_t)wave*np2cap;
+	uint32_t *part = part_all + wave*64;
+	const uint32_t n = min(seq_count[seq], cap);
+	uint32_t np2 = 1; while(np2 < n) np2 <<= 1;
+	for(uint32_t i = lane;i < np2;i += 64){
+		uint64_t k = ~0ull;
+		if(i < n){
+			const Hit h = hits[(size_t)seq*cap + i];
+			if(((epoch << 8) | h.cnt) == best[(size_t)seq*ncand + h.cand]) k = h.key;
+		}
+		fin_keys[i] = k;
+	}
+	wave_sync();
+	for(uint32_t k = 2;k <= np2;k <<= 1){
+		for(uint32_t j = k >> 1;j > 0;j >>= 1){
+			for(uint32_t i = lane;i < np2;i += 64){
+				const uint32_t l = i ^ j;
+				if(l > i){
+					const uint64_t a = fin_keys[i], b = fin_keys[l];
+					const bool up = ((i & k) == 0);
+					if((a > b) == up){ fin_keys[i] = b; fin_keys[l] = a; }
+				}
+			}
+			wave_sync();
+		}
+	}
+	// distinct, non-sentinel keys -> ranks (each lane owns a contiguous chunk)
+	const uint32_t chunk = (np2 + 63)/64;
+	const uint32_t lo = lane*chunk, hi = min(np2, lo + chunk);
+	uint32_t cnt = 0;
+	for(uint32_t i = lo;i < hi;++i){
+		const uint64_t k = fin_keys[i];
+		if(k != ~0ull && (i == 0 || fin_keys[i - 1] != k)) ++cnt;
+	}
+	part[lane] = cnt;
+	wave_sync();
+	if(lane == 0){
+		uint32_t run = 0;
+		for(int t = 0;t < 64;++t){ const uint32_t c = part[t]; part[t] = run; run += c; }
+		seg_hi[seq] = seq*cap + run;
+	}
+	wave_sync();
+	uint32_t rank = part[lane];
+	for(uint32_t i = lo;i < hi;++i){
+		const uint64_t k = fin_keys[i];
+		if(k != ~0ull && (i == 0 || fin_keys[i - 1] != k)){
+			DevEntry e;
+			materialise_entry(k, planes, blk_off, irr, irr_off, e);
+			db[(size_t)seq*cap + rank] = e;
+			++rank;
+		}
+	}
 }
 
 // ============================================================================== amplicon screen
 // match_words (optimize.cpp:291-301) of every assay oligo against every DB entry:
 // mask[e][o/32] bit o%32 = entry matches oligo o at or above unsigned(size*thr^2).
-__global__ void k_match(const DevEntry *__restrict__ db, uint32_t n, const OligoDev *__restrict__ oligos,
-	uint32_t n_oligo, uint32_t mask_words, uint32_t *__restrict__ mask)
+// DB threads: thread g covers slot g%cap of the (g/cap)-th touched sequence.
+__device__ __forceinline__ bool db_slot(uint32_t g, uint32_t n, uint32_t cap, const uint32_t *__restrict__ touched,
+	const uint32_t *__restrict__ seg_hi, uint32_t &slot)
 {
-	const uint32_t i = blockIdx.x*blockDim.x + threadIdx.x;
-	if(i >= n) return;
+	if(g >= n) return false;
+	const uint32_t seq = touched[g/cap];
+	slot = seq*cap + g % cap;
+	return slot < seg_hi[seq];
+}
+
+__global__ void k_match(const DevEntry *__restrict__ db, uint32_t n, uint32_t cap, const uint32_t *__restrict__ touched,
+	const uint32_t *__restrict__ seg_hi, const OligoDev *__restrict__ oligos, uint32_t n_oligo, uint32_t mask_words, uint32_t *__restrict__ mask,
+	uint32_t *__restrict__ status)
+{
+	const uint32_t t = blockIdx.x*blockDim.x + threadIdx.x;
+	if(t == 0 && status) status[0] = 0;
+	uint32_t i;                                // DB slot; slot i belongs to sequence i/cap, filled range [seq*cap, seg_hi[seq])
+	if(!db_slot(t, n, cap, touched, seg_hi, i)) return;
 	const DevEntry e = db[i];
 	for(uint32_t w = 0;w < mask_words;++w){
 		uint32_t bits = 0;
@@ -391,14 +471,15 @@ __device__ bool has_split(const uint4 *__restrict__ planes, uint64_t base, int32
 // One lane per plus-strand DB entry i; it walks the later entries j of the same sequence
 // (sorted by WordMatch::loc, as assay.h:48-61) and, for every assay pair matched by both,
 // applies find_amplicon_match (pcr_assay.cpp:338-441) and the identity test.
-__global__ void k_pair(const DevEntry *__restrict__ db, uint32_t n, const uint32_t *__restrict__ seg_hi,
-	const uint32_t *__restrict__ mask, uint32_t mask_words, const OligoDev *__restrict__ oligos, uint32_t n_pairs,
+__global__ void k_pair(const DevEntry *__restrict__ db, uint32_t n, uint32_t cap, const uint32_t *__restrict__ touched,
+	const uint32_t *__restrict__ seg_hi, const uint32_t *__restrict__ mask, uint32_t mask_words, const OligoDev *__restrict__ oligos, uint32_t n_pairs,
 	const uint4 *__restrict__ planes, const uint64_t *__restrict__ blk_off, const uint64_t *__restrict__ len,
 	const uint8_t *__restrict__ active, int32_t amp_min, int32_t amp_max, float ident_thr, int use_taq,
 	uint64_t *__restrict__ bits_fr, uint64_t *__restrict__ bits_rf, uint64_t bit_words, uint32_t *__restrict__ status)
 {
-	const uint32_t i = blockIdx.x*blockDim.x + threadIdx.x;
-	if(i >= n) return;
+	const uint32_t t = blockIdx.x*blockDim.x + threadIdx.x;
+	uint32_t i;
+	if(!db_slot(t, n, cap, touched, seg_hi, i)) return;
 	const DevEntry ei = db[i];
 	if(ei.strand != 1) return;
 	if(!active[ei.seq]) return;                                                  // optimize.cpp:281
@@ -484,13 +565,19 @@ struct SeqSet {
 	DevBuf<uint8_t> codes; DevBuf<uint64_t> d_code_off; bool have_codes = false;
 	// word DB of the last select
 	bool have_db = false;
-	uint32_t n_entries = 0;
+	uint32_t n_entries = 0;     // DB entries over all sequences
+	uint32_t db_cap = 0;        // slots per sequence in `db`; the entries of sequence s are db[s*db_cap .. seg_hi[s])
+	uint64_t n_slots = 0;       // n * db_cap
 	DevBuf<DevEntry> db;
+	DevBuf<uint32_t> touched;     // sequences holding DB entries (arrival order)
+	DevBuf<uint32_t> ctrl;        // [0..7] counters | [8, 8+n) per-sequence hit counts | [8+n, 8+2n) seg_hi : one memset per pass
+	uint32_t n_touched = 0;
+	uint32_t *d_seg_hi = nullptr;
 	void release()
 	{
 		planes.release(); valid.release(); nib.release(); blk_seq.release(); tile_seq.release(); tile_pos0.release();
 		irr_off.release(); seg_lo.release(); seg_hi.release(); d_len.release(); d_blk_off.release();
-		d_nblk_real.release(); d_active.release(); irr.release(); db.release(); codes.release(); d_code_off.release();
+		d_nblk_real.release(); d_active.release(); irr.release(); db.release(); touched.release(); ctrl.release(); codes.release(); d_code_off.release();
 	}
 };
 
@@ -508,15 +595,20 @@ struct pcr_ctx {
 	DevBuf<uint32_t> cand_floor, best, counters, mask, status, tab, bias;
 	int scan_version = 2;
 	DevBuf<Hit> hits;
-	DevBuf<uint64_t> keys, keys_sorted, keys_unique, bits_fr, bits_rf;
-	DevBuf<uint8_t> cub_tmp;
-	DevBuf<uint32_t> n_unique;
+	DevBuf<uint64_t> bits_fr, bits_rf;
 	DevBuf<OligoDev> oligos;
 	DevBuf<SwJob> sw_jobs; DevBuf<SwOut> sw_out; DevBuf<uint8_t> sw_q, sw_qlen, sw_t, entry_codes, entry_lens;
 	DevBuf<AmpRec> amp_recs; DevBuf<BgPairDev> bg_pairs;
 	DevBuf<thermo::Job> th_jobs; DevBuf<thermo::JobOut> th_out; DevBuf<int> th_dg, th_scratch_i; DevBuf<unsigned short> th_scratch_s;
 	size_t amp_cap = size_t(1) << 20;
-	size_t hit_cap = size_t(1) << 22;
+	uint32_t bucket_cap = 64;   // hit slots per sequence (grows on overflow)
+	uint32_t epoch = 0;         // pass counter tagging best[] (see HitSink)
+	uint32_t *best_seen = nullptr;
+	// pinned staging for the small per-call host->device payload (candidates, tables, oligos): one async copy
+	uint8_t *stage = nullptr; size_t stage_cap = 0; hipEvent_t stage_done = nullptr; bool stage_busy = false;
+	DevBuf<uint8_t> arena;
+	const uint4 *d_cand_fwd = nullptr, *d_cand_rc = nullptr; const uint32_t *d_cand_floor = nullptr, *d_tab = nullptr, *d_bias = nullptr;
+	const OligoDev *d_oligos = nullptr;
 	// profiling
 	bool prof = false;
 	std::vector<std::pair<hipEvent_t, hipEvent_t> > prof_events;
@@ -574,13 +666,54 @@ void fill_oligo(OligoDev &o, const uint64_t w[2], float thr2)
 	o.p2 = (o.stop >= 0) ? pcrhost::planes_nibble(o.m, o.stop) : 0;
 }
 
+// Packs small host arrays into the pinned staging buffer and ships them with ONE async copy.
+struct Stager {
+	pcr_ctx *ctx; size_t used = 0;
+	explicit Stager(pcr_ctx *c) : ctx(c) {}
+	int begin(size_t bytes)
+	{
+		if(ctx->stage_busy){ HIP_TRY(hipEventSynchronize(ctx->stage_done)); ctx->stage_busy = false; }
+		if(bytes > ctx->stage_cap){
+			if(ctx->stage){ (void)hipHostFree(ctx->stage); ctx->stage = nullptr; ctx->stage_cap = 0; }
+			const size_t want = std::max<size_t>(bytes*2, 1 << 16);
+			HIP_TRY(hipHostMalloc((void **)&ctx->stage, want, hipHostMallocDefault));
+			ctx->stage_cap = want;
+		}
+		if(!ctx->stage_done) HIP_TRY(hipEventCreateWithFlags(&ctx->stage_done, hipEventDisableTiming));
+		int rc = ctx->arena.ensure(bytes + 256);
+		used = 0;
+		return rc;
+	}
+	// returns the DEVICE address the bytes will have
+	template<class T> T *put(const T *src, size_t n)
+	{
+		used = (used + 15) & ~size_t(15);
+		memcpy(ctx->stage + used, src, n*sizeof(T));
+		T *dev = (T *)(ctx->arena.p + used);
+		used += n*sizeof(T);
+		return dev;
+	}
+	int ship()
+	{
+		if(used) HIP_TRY(hipMemcpyAsync(ctx->arena.p, ctx->stage, used, hipMemcpyHostToDevice, ctx->stream));
+		HIP_TRY(hipEventRecord(ctx->stage_done, ctx->stream));
+		ctx->stage_busy = true;
+		return PCR_OK;
+	}
+};
+
 int amplify_launch(pcr_ctx *ctx, SeqSet &S, const pcr_pair *pairs, uint32_t n_pairs, const pcr_amplify_args *a,
 	uint64_t *d_fr, uint64_t *d_rf)
 {
 	if(!S.have_db){ g_err = "pcr_amplify: no word DB (call pcr_select_words first)"; return PCR_ERR_STATE; }
 	const uint64_t words = (S.n + 63)/64;
-	HIP_TRY(hipMemsetAsync(d_fr, 0, (size_t)n_pairs*words*sizeof(uint64_t), ctx->stream));
-	HIP_TRY(hipMemsetAsync(d_rf, 0, (size_t)n_pairs*words*sizeof(uint64_t), ctx->stream));
+	if(d_rf == d_fr + (size_t)n_pairs*words){
+		HIP_TRY(hipMemsetAsync(d_fr, 0, 2*(size_t)n_pairs*words*sizeof(uint64_t), ctx->stream));
+	}
+	else{
+		HIP_TRY(hipMemsetAsync(d_fr, 0, (size_t)n_pairs*words*sizeof(uint64_t), ctx->stream));
+		HIP_TRY(hipMemsetAsync(d_rf, 0, (size_t)n_pairs*words*sizeof(uint64_t), ctx->stream));
+	}
 	if(S.n_entries == 0 || n_pairs == 0) return PCR_OK;
 	const float thr2 = a->collect_threshold*a->collect_threshold;                // pcr_assay.cpp:31-32
 	std::vector<OligoDev> ol(2*(size_t)n_pairs);
@@ -589,31 +722,32 @@ int amplify_launch(pcr_ctx *ctx, SeqSet &S, const pcr_pair *pairs, uint32_t n_pa
 		fill_oligo(ol[2*i + 1], pairs[i].r.w, thr2);
 	}
 	int rc;
-	if((rc = ctx->oligos.ensure(ol.size())) != PCR_OK) return rc;
-	HIP_TRY(hipMemcpyAsync(ctx->oligos.p, ol.data(), ol.size()*sizeof(OligoDev), hipMemcpyHostToDevice, ctx->stream));
-	HIP_TRY(hipStreamSynchronize(ctx->stream));   // `ol` is a stack-lifetime staging buffer
+	Stager st(ctx);
+	if((rc = st.begin(ol.size()*sizeof(OligoDev) + 64)) != PCR_OK) return rc;
+	ctx->d_oligos = st.put(ol.data(), ol.size());
+	if((rc = st.ship()) != PCR_OK) return rc;
 	const uint32_t mask_words = (2*n_pairs + 31)/32;
-	if((rc = ctx->mask.ensure((size_t)S.n_entries*mask_words)) != PCR_OK) return rc;
+	if((rc = ctx->mask.ensure((size_t)S.n_slots*mask_words)) != PCR_OK) return rc;
 	if((rc = ctx->status.ensure(1)) != PCR_OK) return rc;
-	HIP_TRY(hipMemsetAsync(ctx->status.p, 0, sizeof(uint32_t), ctx->stream));
 	const unsigned threads = 128;
-	const unsigned grid = (S.n_entries + threads - 1)/threads;
-	hipLaunchKernelGGL(k_match, dim3(grid), dim3(threads), 0, ctx->stream, S.db.p, S.n_entries, ctx->oligos.p,
-		2*n_pairs, mask_words, ctx->mask.p);
+	const uint32_t n_db = S.n_touched*S.db_cap;
+	const unsigned grid = (n_db + threads - 1)/threads;
+	// k_match also clears the status word (it runs before k_pair in stream order)
+	hipLaunchKernelGGL(k_match, dim3(grid), dim3(threads), 0, ctx->stream, S.db.p, n_db, S.db_cap, S.touched.p, S.d_seg_hi, ctx->d_oligos,
+		2*n_pairs, mask_words, ctx->mask.p, ctx->status.p);
 	HIP_TRY(hipGetLastError());
-	hipLaunchKernelGGL(k_pair, dim3(grid), dim3(threads), 0, ctx->stream, S.db.p, S.n_entries, S.seg_hi.p, ctx->mask.p,
-		mask_words, ctx->oligos.p, n_pairs, S.planes.p, S.d_blk_off.p, S.d_len.p, S.d_active.p, a->amp_min, a->amp_max,
+	hipLaunchKernelGGL(k_pair, dim3(grid), dim3(threads), 0, ctx->stream, S.db.p, n_db, S.db_cap, S.touched.p, S.d_seg_hi, ctx->mask.p,
+		mask_words, ctx->d_oligos, n_pairs, S.planes.p, S.d_blk_off.p, S.d_len.p, S.d_active.p, a->amp_min, a->amp_max,
 		a->ident_threshold, a->use_taq_mama, d_fr, d_rf, words, ctx->status.p);
 	HIP_TRY(hipGetLastError());
 	return PCR_OK;
 }
 
 template<int NSLOT, int KLO>
-int launch_scan2_nw(pcr_ctx *ctx, SeqSet &S, uint32_t nw, uint32_t group0, uint32_t n_groups, uint32_t ncand)
+int launch_scan2_nw(pcr_ctx *ctx, SeqSet &S, uint32_t nw, uint32_t group0, uint32_t n_groups, uint32_t ncand, const HitSink &sink)
 {
 #define SCAN2_ARGS S.nib.p, S.planes.p, S.valid.p, S.d_blk_off.p, S.d_len.p, S.d_active.p, S.tile_seq.p, S.tile_pos0.p, \
-	ctx->tab.p, ctx->bias.p, group0, ctx->cand_fwd.p, ctx->cand_rc.p, ctx->cand_floor.p, ncand, ctx->best.p, ctx->hits.p, \
-	ctx->counters.p, (uint32_t)ctx->hit_cap
+	ctx->d_tab, ctx->d_bias, group0, ctx->d_cand_fwd, ctx->d_cand_rc, ctx->d_cand_floor, ncand, sink
 	const dim3 grid(S.n_tiles, n_groups), block(SCAN2_THREADS);
 	switch(nw){
 		case 1: hipLaunchKernelGGL((k_scan2<1, NSLOT, KLO>), grid, block, 0, ctx->stream, SCAN2_ARGS); break;
@@ -632,19 +766,34 @@ int launch_scan2_nw(pcr_ctx *ctx, SeqSet &S, uint32_t nw, uint32_t group0, uint3
 
 // The bit-sliced scan over all orientation groups: full groups (8 words) in one launch, the
 // partial last group in a second one.
-int launch_scan2(pcr_ctx *ctx, SeqSet &S, const Scan2Tables &T, uint32_t ncand)
+int launch_scan2(pcr_ctx *ctx, SeqSet &S, const Scan2Tables &T, uint32_t ncand, const HitSink &sink)
 {
 	const uint32_t full = (T.last_words == 8) ? T.n_groups : T.n_groups - 1;
 	int rc = PCR_OK;
 	if(full){
-		rc = (T.nslot == 26) ? launch_scan2_nw<26, 3>(ctx, S, 8, 0, full, ncand) : launch_scan2_nw<32, 0>(ctx, S, 8, 0, full, ncand);
+		rc = (T.nslot == 26) ? launch_scan2_nw<26, 3>(ctx, S, 8, 0, full, ncand, sink) : launch_scan2_nw<32, 0>(ctx, S, 8, 0, full, ncand, sink);
 		if(rc != PCR_OK) return rc;
 	}
 	if(full < T.n_groups){
-		rc = (T.nslot == 26) ? launch_scan2_nw<26, 3>(ctx, S, T.last_words, full, 1, ncand)
-			: launch_scan2_nw<32, 0>(ctx, S, T.last_words, full, 1, ncand);
+		rc = (T.nslot == 26) ? launch_scan2_nw<26, 3>(ctx, S, T.last_words, full, 1, ncand, sink)
+			: launch_scan2_nw<32, 0>(ctx, S, T.last_words, full, 1, ncand, sink);
 	}
 	return rc;
+}
+
+// Exact DB size: sum of the per-sequence fills (done on the host on request; a device-side
+// same-address atomic per sequence would serialise, ~35 ns each).
+int count_entries(pcr_ctx *ctx, SeqSet &S)
+{
+	uint64_t total = 0;
+	if(S.n_touched){
+		std::vector<uint32_t> hi(S.n);
+		HIP_TRY(hipMemcpyAsync(hi.data(), S.d_seg_hi, S.n*sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(hipStreamSynchronize(ctx->stream));
+		for(uint32_t q = 0;q < S.n;++q){ if(hi[q]) total += hi[q] - (uint64_t)q*S.db_cap; }
+	}
+	S.n_entries = (uint32_t)total;
+	return PCR_OK;
 }
 
 } // namespace
@@ -704,9 +853,11 @@ void pcr_destroy(pcr_ctx *ctx)
 	for(auto &pr : ctx->prof_events){ (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
 	for(int s = 0;s < 2;++s) ctx->sets[s].release();
 	ctx->cand_fwd.release(); ctx->cand_rc.release(); ctx->cand_floor.release(); ctx->best.release();
-	ctx->counters.release(); ctx->mask.release(); ctx->status.release(); ctx->hits.release(); ctx->keys.release();
-	ctx->keys_sorted.release(); ctx->keys_unique.release(); ctx->bits_fr.release(); ctx->bits_rf.release();
-	ctx->cub_tmp.release(); ctx->n_unique.release(); ctx->oligos.release(); ctx->tab.release(); ctx->bias.release(); ctx->sw_jobs.release(); ctx->sw_out.release(); ctx->sw_q.release(); ctx->sw_qlen.release(); ctx->sw_t.release(); ctx->entry_codes.release(); ctx->entry_lens.release(); ctx->amp_recs.release(); ctx->bg_pairs.release(); ctx->th_jobs.release(); ctx->th_out.release(); ctx->th_dg.release(); ctx->th_scratch_i.release(); ctx->th_scratch_s.release();
+	ctx->counters.release(); ctx->mask.release(); ctx->status.release(); ctx->hits.release();
+	ctx->bits_fr.release(); ctx->bits_rf.release(); ctx->arena.release();
+	if(ctx->stage) (void)hipHostFree(ctx->stage);
+	if(ctx->stage_done) (void)hipEventDestroy(ctx->stage_done);
+	ctx->oligos.release(); ctx->tab.release(); ctx->bias.release(); ctx->sw_jobs.release(); ctx->sw_out.release(); ctx->sw_q.release(); ctx->sw_qlen.release(); ctx->sw_t.release(); ctx->entry_codes.release(); ctx->entry_lens.release(); ctx->amp_recs.release(); ctx->bg_pairs.release(); ctx->th_jobs.release(); ctx->th_out.release(); ctx->th_dg.release(); ctx->th_scratch_i.release(); ctx->th_scratch_s.release();
 	if(ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
@@ -879,30 +1030,44 @@ int pcr_select_words(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_
 		hfl[c] = cand[c].floor_;
 	}
 	int rc;
-	if((rc = ctx->cand_fwd.ensure(ncand)) != PCR_OK) return rc;
-	if((rc = ctx->cand_rc.ensure(ncand)) != PCR_OK) return rc;
-	if((rc = ctx->cand_floor.ensure(ncand)) != PCR_OK) return rc;
 	if((rc = ctx->best.ensure((size_t)S.n*ncand)) != PCR_OK) return rc;
-	if((rc = ctx->counters.ensure(4)) != PCR_OK) return rc;
-	HIP_TRY(hipMemcpyAsync(ctx->cand_fwd.p, hf.data(), ncand*sizeof(uint4), hipMemcpyHostToDevice, ctx->stream));
-	HIP_TRY(hipMemcpyAsync(ctx->cand_rc.p, hr.data(), ncand*sizeof(uint4), hipMemcpyHostToDevice, ctx->stream));
-	HIP_TRY(hipMemcpyAsync(ctx->cand_floor.p, hfl.data(), ncand*sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-
+	if(ctx->best.p != ctx->best_seen || ctx->epoch >= (1u << 24) - 2){
+		// fresh (uninitialised) storage or epoch wrap: clear once; afterwards the epoch tag makes clearing unnecessary
+		HIP_TRY(hipMemsetAsync(ctx->best.p, 0, ctx->best.cap*sizeof(uint32_t), ctx->stream));
+		ctx->best_seen = ctx->best.p; ctx->epoch = 0;
+	}
 	Scan2Tables tables;
-	if(ctx->scan_version != 1){
-		build_scan2_tables(cand, tables);
-		if((rc = ctx->tab.ensure(tables.tab.size())) != PCR_OK) return rc;
-		if((rc = ctx->bias.ensure(tables.bias.size())) != PCR_OK) return rc;
-		HIP_TRY(hipMemcpyAsync(ctx->tab.p, tables.tab.data(), tables.tab.size()*sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-		HIP_TRY(hipMemcpyAsync(ctx->bias.p, tables.bias.data(), tables.bias.size()*sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+	if(ctx->scan_version != 1) build_scan2_tables(cand, tables);
+	{
+		Stager st(ctx);
+		if((rc = st.begin(ncand*(2*sizeof(uint4) + sizeof(uint32_t)) + (tables.tab.size() + tables.bias.size())*sizeof(uint32_t) + 256)) != PCR_OK) return rc;
+		ctx->d_cand_fwd = st.put(hf.data(), ncand);
+		ctx->d_cand_rc = st.put(hr.data(), ncand);
+		ctx->d_cand_floor = st.put(hfl.data(), ncand);
+		if(ctx->scan_version != 1){
+			ctx->d_tab = st.put(tables.tab.data(), tables.tab.size());
+			ctx->d_bias = st.put(tables.bias.data(), tables.bias.size());
+		}
+		if((rc = st.ship()) != PCR_OK) return rc;
 	}
 
 	uint32_t h_counters[4];
+	if((rc = S.ctrl.ensure(8 + 2*(size_t)S.n)) != PCR_OK) return rc;
+	if((rc = S.touched.ensure(S.n)) != PCR_OK) return rc;
+	uint32_t *const d_counters = S.ctrl.p, *const d_seq_count = S.ctrl.p + 8;
+	S.d_seg_hi = S.ctrl.p + 8 + S.n;
 	for(int attempt = 0;;++attempt){
-		if((rc = ctx->hits.ensure(ctx->hit_cap)) != PCR_OK) return rc;
-		if((rc = ctx->keys.ensure(ctx->hit_cap)) != PCR_OK) return rc;
-		HIP_TRY(hipMemsetAsync(ctx->best.p, 0, (size_t)S.n*ncand*sizeof(uint32_t), ctx->stream));
-		HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, 4*sizeof(uint32_t), ctx->stream));
+		const uint32_t cap = ctx->bucket_cap;
+		const uint64_t n_slots = (uint64_t)S.n*cap;
+		if(n_slots >= (uint64_t(1) << 32) || n_slots*(sizeof(Hit) + sizeof(DevEntry)) > (uint64_t(96) << 30)){
+			g_err = "pcr_select_words: the per-sequence hit buckets would not fit (too many tied sites per sequence)"; return PCR_ERR_CAPACITY;
+		}
+		if((rc = ctx->hits.ensure(n_slots)) != PCR_OK) return rc;
+		if((rc = S.db.ensure(n_slots)) != PCR_OK) return rc;
+		HIP_TRY(hipMemsetAsync(S.ctrl.p, 0, (8 + 2*(size_t)S.n)*sizeof(uint32_t), ctx->stream));
+		++ctx->epoch;
+		HitSink sink; sink.best = ctx->best.p; sink.hits = ctx->hits.p; sink.seq_count = d_seq_count;
+		sink.counters = d_counters; sink.touched = S.touched.p; sink.cap = cap; sink.ncand = ncand; sink.epoch = ctx->epoch;
 		if(S.n_tiles){
 			hipEvent_t e0 = nullptr, e1 = nullptr;
 			if(ctx->prof){
@@ -911,12 +1076,12 @@ int pcr_select_words(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_
 			}
 			if(ctx->scan_version == 1){
 				hipLaunchKernelGGL(k_scan, dim3(S.n_tiles), dim3(SCAN_THREADS), 0, ctx->stream, S.planes.p, S.valid.p,
-					S.d_blk_off.p, S.d_len.p, S.d_active.p, S.tile_seq.p, S.tile_pos0.p, ctx->cand_fwd.p, ctx->cand_rc.p,
-					ctx->cand_floor.p, ncand, ctx->best.p, ctx->hits.p, ctx->counters.p, (uint32_t)ctx->hit_cap);
+					S.d_blk_off.p, S.d_len.p, S.d_active.p, S.tile_seq.p, S.tile_pos0.p, ctx->d_cand_fwd, ctx->d_cand_rc,
+					ctx->d_cand_floor, ncand, sink);
 				HIP_TRY(hipGetLastError());
 			}
 			else{
-				if((rc = launch_scan2(ctx, S, tables, ncand)) != PCR_OK) return rc;
+				if((rc = launch_scan2(ctx, S, tables, ncand, sink)) != PCR_OK) return rc;
 			}
 			if(ctx->prof){
 				HIP_TRY(hipEventRecord(e1, ctx->stream));
@@ -924,56 +1089,34 @@ int pcr_select_words(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_
 			}
 		}
 		if(S.n_irr){
-			const unsigned threads = 64;
-			hipLaunchKernelGGL(k_scan_irr, dim3((S.n_irr + threads - 1)/threads), dim3(threads), 0, ctx->stream, S.irr.p,
-				S.n_irr, S.d_active.p, min_oligo_length, ctx->cand_fwd.p, ctx->cand_floor.p, ncand, ctx->best.p,
-				ctx->hits.p, ctx->counters.p, (uint32_t)ctx->hit_cap);
+			const unsigned irr_grid = std::min<unsigned>((S.n_irr + IRR_THREADS - 1)/IRR_THREADS, 1024u);
+			hipLaunchKernelGGL(k_scan_irr, dim3(irr_grid), dim3(IRR_THREADS), 0, ctx->stream, S.irr.p,
+				S.n_irr, S.d_active.p, min_oligo_length, ctx->d_cand_fwd, ctx->d_cand_floor, ncand, sink);
 			HIP_TRY(hipGetLastError());
 		}
-		HIP_TRY(hipMemcpyAsync(h_counters, ctx->counters.p, sizeof(h_counters), hipMemcpyDeviceToHost, ctx->stream));
-		HIP_TRY(hipStreamSynchronize(ctx->stream));
-		if(h_counters[0] <= ctx->hit_cap) break;
-		// the hit list overflowed: grow and redo the pass
-		if(attempt >= 6 || (size_t)h_counters[0] > (size_t(1) << 31)){ g_err = "pcr_select_words: hit list does not fit"; return PCR_ERR_CAPACITY; }
-		ctx->hit_cap = std::max<size_t>(ctx->hit_cap*2, (size_t)h_counters[0] + (h_counters[0] >> 2));
-	}
-	const uint32_t n_hits = h_counters[0];
-	uint32_t n_keys = 0, n_unique = 0;
-	if(n_hits){
-		const unsigned threads = 256;
-		hipLaunchKernelGGL(k_filter, dim3((n_hits + threads - 1)/threads), dim3(threads), 0, ctx->stream, ctx->hits.p, n_hits,
-			ctx->best.p, ncand, ctx->keys.p, ctx->counters.p);
+		uint32_t np2 = 1; while(np2 < cap) np2 <<= 1;
+		hipLaunchKernelGGL(k_finalize, dim3((S.n + FIN_WAVES - 1)/FIN_WAVES), dim3(FIN_THREADS), (size_t)FIN_WAVES*np2*sizeof(uint64_t), ctx->stream,
+			ctx->hits.p, d_seq_count, cap, ctx->best.p, ncand, S.planes.p, S.d_blk_off.p, S.irr.p, S.irr_off.p, S.db.p, S.d_seg_hi,
+			d_counters, ctx->epoch, S.touched.p);
 		HIP_TRY(hipGetLastError());
-		HIP_TRY(hipMemcpyAsync(h_counters, ctx->counters.p, sizeof(h_counters), hipMemcpyDeviceToHost, ctx->stream));
+		// the only host synchronisation of the pass: overflow flag + DB size
+		HIP_TRY(hipMemcpyAsync(h_counters, d_counters, sizeof(h_counters), hipMemcpyDeviceToHost, ctx->stream));
 		HIP_TRY(hipStreamSynchronize(ctx->stream));
-		n_keys = h_counters[1];
+		S.db_cap = cap; S.n_slots = n_slots;
+		if(!(h_counters[0] & 1u)) break;
+		// some sequence collected more hits than its bucket holds: grow the buckets and redo the pass
+		if(attempt >= 8 || cap >= 1024){ g_err = "pcr_select_words: more than 1024 tied candidate sites in one sequence (per-sequence bucket limit)"; return PCR_ERR_CAPACITY; }
+		uint32_t want = cap*2;
+		while(want < h_counters[2] && want < 1024) want *= 2;
+		ctx->bucket_cap = want;
 	}
-	if(n_keys){
-		if((rc = ctx->keys_sorted.ensure(n_keys)) != PCR_OK) return rc;
-		if((rc = ctx->keys_unique.ensure(n_keys)) != PCR_OK) return rc;
-		if((rc = ctx->n_unique.ensure(1)) != PCR_OK) return rc;
-		size_t tmp1 = 0, tmp2 = 0;
-		HIP_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp1, ctx->keys.p, ctx->keys_sorted.p, (int)n_keys, 0, 64, ctx->stream));
-		HIP_TRY(hipcub::DeviceSelect::Unique(nullptr, tmp2, ctx->keys_sorted.p, ctx->keys_unique.p, ctx->n_unique.p, (int)n_keys, ctx->stream));
-		size_t tmp = std::max(tmp1, tmp2);
-		if((rc = ctx->cub_tmp.ensure(tmp)) != PCR_OK) return rc;
-		HIP_TRY(hipcub::DeviceRadixSort::SortKeys(ctx->cub_tmp.p, tmp1, ctx->keys.p, ctx->keys_sorted.p, (int)n_keys, 0, 64, ctx->stream));
-		HIP_TRY(hipcub::DeviceSelect::Unique(ctx->cub_tmp.p, tmp2, ctx->keys_sorted.p, ctx->keys_unique.p, ctx->n_unique.p, (int)n_keys, ctx->stream));
-		HIP_TRY(hipMemcpyAsync(&n_unique, ctx->n_unique.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-		HIP_TRY(hipStreamSynchronize(ctx->stream));
-	}
-	HIP_TRY(hipMemsetAsync(S.seg_lo.p, 0, S.n*sizeof(uint32_t), ctx->stream));
-	HIP_TRY(hipMemsetAsync(S.seg_hi.p, 0, S.n*sizeof(uint32_t), ctx->stream));
-	if(n_unique){
-		if((rc = S.db.ensure(n_unique)) != PCR_OK) return rc;
-		const unsigned threads = 256;
-		hipLaunchKernelGGL(k_entries, dim3((n_unique + threads - 1)/threads), dim3(threads), 0, ctx->stream, ctx->keys_unique.p,
-			n_unique, S.planes.p, S.d_blk_off.p, S.irr.p, S.irr_off.p, S.db.p, S.seg_lo.p, S.seg_hi.p);
-		HIP_TRY(hipGetLastError());
-	}
-	S.n_entries = n_unique;
+	S.n_touched = h_counters[3];
+	S.n_entries = S.n_touched ? 1 : 0;   // "non-empty" marker; the exact count is taken on demand (count_entries)
 	S.have_db = true;
-	if(n_entries_out) *n_entries_out = n_unique;
+	if(n_entries_out){
+		if((rc = count_entries(ctx, S)) != PCR_OK) return rc;
+		*n_entries_out = S.n_entries;
+	}
 	return PCR_OK;
 }
 
@@ -982,15 +1125,20 @@ int64_t pcr_get_entries(pcr_ctx *ctx, pcr_set which, pcr_entry *out, uint64_t ca
 	if(!ctx){ g_err = "null ctx"; return PCR_ERR_ARG; }
 	SeqSet &S = ctx->sets[which];
 	if(!S.have_db){ g_err = "pcr_get_entries: no word DB"; return PCR_ERR_STATE; }
-	const uint64_t n = std::min<uint64_t>(cap, S.n_entries);
-	if(n && out){
-		std::vector<DevEntry> h(n);
+	{ const int rc = count_entries(ctx, S); if(rc != PCR_OK) return rc; }
+	if(cap && out && S.n_entries){
+		std::vector<DevEntry> h(S.n_slots);
+		std::vector<uint32_t> hi(S.n);
 		hipError_t e = hipStreamSynchronize(ctx->stream);
-		if(e == hipSuccess) e = hipMemcpy(h.data(), S.db.p, n*sizeof(DevEntry), hipMemcpyDeviceToHost);
+		if(e == hipSuccess) e = hipMemcpy(h.data(), S.db.p, S.n_slots*sizeof(DevEntry), hipMemcpyDeviceToHost);
+		if(e == hipSuccess) e = hipMemcpy(hi.data(), S.d_seg_hi, S.n*sizeof(uint32_t), hipMemcpyDeviceToHost);
 		if(e != hipSuccess){ g_err = std::string("pcr_get_entries: ") + hipGetErrorString(e); return PCR_ERR_DEVICE; }
-		for(uint64_t i = 0;i < n;++i){
-			pcrhost::word_of_planes(h[i].w, out[i].word.w);
-			out[i].loc = h[i].loc; out[i].index = h[i].seq; out[i].strand = h[i].strand; out[i].pad = 0;
+		uint64_t k = 0;
+		for(uint32_t q = 0;q < S.n && k < cap;++q){
+			for(uint32_t i = q*S.db_cap;i < hi[q] && k < cap;++i, ++k){
+				pcrhost::word_of_planes(h[i].w, out[k].word.w);
+				out[k].loc = h[i].loc; out[k].index = h[i].seq; out[k].strand = h[i].strand; out[k].pad = 0;
+			}
 		}
 	}
 	return (int64_t)S.n_entries;
@@ -1256,20 +1404,21 @@ int pcr_background_match(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uin
 	HIP_TRY(hipStreamSynchronize(ctx->stream));
 	if((rc = upload_pair_queries(ctx, pairs, n_pairs)) != PCR_OK) return rc;
 	const uint32_t mask_words = (2*n_pairs + 31)/32;
-	if((rc = ctx->mask.ensure((size_t)S.n_entries*mask_words)) != PCR_OK) return rc;
+	if((rc = ctx->mask.ensure((size_t)S.n_slots*mask_words)) != PCR_OK) return rc;
 	if((rc = ctx->status.ensure(1)) != PCR_OK) return rc;
 	if((rc = ctx->counters.ensure(4)) != PCR_OK) return rc;
 	if((rc = ctx->bits_fr.ensure(total)) != PCR_OK) return rc;
 	const unsigned threads = 128;
-	const unsigned grid = (S.n_entries + threads - 1)/threads;
-	hipLaunchKernelGGL(k_match, dim3(grid), dim3(threads), 0, ctx->stream, S.db.p, S.n_entries, ctx->oligos.p, 2*n_pairs, mask_words, ctx->mask.p);
+	const uint32_t n_db = S.n_touched*S.db_cap;
+	const unsigned grid = (n_db + threads - 1)/threads;
+	hipLaunchKernelGGL(k_match, dim3(grid), dim3(threads), 0, ctx->stream, S.db.p, n_db, S.db_cap, S.touched.p, S.d_seg_hi, ctx->oligos.p, 2*n_pairs, mask_words, ctx->mask.p, (uint32_t *)nullptr);
 	HIP_TRY(hipGetLastError());
 	uint32_t n_amp = 0, status = 0;
 	for(int attempt = 0;;++attempt){
 		if((rc = ctx->amp_recs.ensure(ctx->amp_cap)) != PCR_OK) return rc;
 		HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, 4*sizeof(uint32_t), ctx->stream));
 		HIP_TRY(hipMemsetAsync(ctx->status.p, 0, sizeof(uint32_t), ctx->stream));
-		hipLaunchKernelGGL(k_pair_emit, dim3(grid), dim3(threads), 0, ctx->stream, S.db.p, S.n_entries, S.seg_hi.p, ctx->mask.p, mask_words,
+		hipLaunchKernelGGL(k_pair_emit, dim3(grid), dim3(threads), 0, ctx->stream, S.db.p, n_db, S.db_cap, S.touched.p, S.d_seg_hi, ctx->mask.p, mask_words,
 			ctx->oligos.p, n_pairs, S.planes.p, S.d_blk_off.p, S.d_len.p, S.d_active.p, args->amp_min, args->amp_max,
 			ctx->amp_recs.p, (uint32_t)ctx->amp_cap, ctx->counters.p, ctx->status.p);
 		HIP_TRY(hipGetLastError());
@@ -1282,10 +1431,10 @@ int pcr_background_match(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uin
 	}
 	if(status & 1u){ g_err = "Sequence::has_split: range is out of bounds"; return PCR_ERR_RANGE; }
 	if(n_amp == 0) return PCR_OK;
-	if((rc = ctx->entry_codes.ensure((size_t)S.n_entries*32)) != PCR_OK) return rc;
-	if((rc = ctx->entry_lens.ensure(S.n_entries)) != PCR_OK) return rc;
+	if((rc = ctx->entry_codes.ensure((size_t)S.n_slots*32)) != PCR_OK) return rc;
+	if((rc = ctx->entry_lens.ensure(S.n_slots)) != PCR_OK) return rc;
 	if((rc = ctx->sw_jobs.ensure((size_t)n_amp*4)) != PCR_OK) return rc;
-	hipLaunchKernelGGL(k_entry_codes, dim3((S.n_entries*32 + 255)/256), dim3(256), 0, ctx->stream, S.db.p, S.n_entries, ctx->entry_codes.p, ctx->entry_lens.p);
+	hipLaunchKernelGGL(k_entry_codes, dim3((unsigned)(((size_t)n_db*32 + 255)/256)), dim3(256), 0, ctx->stream, S.db.p, n_db, S.db_cap, S.touched.p, S.d_seg_hi, ctx->entry_codes.p, ctx->entry_lens.p);
 	HIP_TRY(hipGetLastError());
 	hipLaunchKernelGGL(k_bg_jobs, dim3((n_amp*4 + 255)/256), dim3(256), 0, ctx->stream, ctx->amp_recs.p, n_amp, ctx->entry_lens.p, ctx->sw_jobs.p);
 	HIP_TRY(hipGetLastError());
