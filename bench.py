@@ -74,6 +74,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--random-primers", action="store_true", help="diagnostic: primers unrelated to the targets (no hits)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--target-threshold", type=float, default=1.0,
+                    help="--target.threshold of the reference (pcramp.h:39 default 1.0)")
+    ap.add_argument("--search-multiplier", type=float, default=0.9,
+                    help="target search multiplier of the reference (pcramp.h:51 default 0.9)")
     args = ap.parse_args()
 
     import torch
@@ -91,7 +95,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev_t = torch.device("cuda", local_rank)
 
-    thr_t, mult = 0.9, 0.9
+    thr_t, mult = args.target_threshold, args.search_multiplier
     select_thr = float(np.float32(thr_t) * np.float32(mult))
 
     # every rank owns a different shard of the same family structure; the primer pairs are

@@ -7,6 +7,7 @@
 //               Each sequence owns ceil(L/32)+2 blocks (two zero halo blocks).
 //   nib[]     : the same codes as 4 u32 per block, nibble j%8 of word j/8 = base 32*b+j (table index of
 //               the bit-sliced scan, pcr_scan_bitsliced.inc).
+//   tb[]      : 2 bits per base (A,C,G,T = 0..3, anything else 0), 2 u32 per block: q-gram codes of the seed scan.
 //   valid[]   : one u32 per block; bit j = the 32-base window starting at 32*b+j is a REGULAR
 //               window that Sequence::pack emits (sequence.cpp:127-153 filters applied).
 //   irr[]     : explicit irregular words (pcr_host.hpp).
@@ -102,7 +103,7 @@ __device__ __forceinline__ uint32_t match_count(uint32_t wa, uint32_t wc, uint32
 // One thread per 32-base block: nibbles (high first, sequence.h:223-228) -> four bit planes.
 __global__ void k_transpose(const uint8_t *__restrict__ packed, const uint64_t *__restrict__ byte_off,
 	const uint64_t *__restrict__ len, const uint64_t *__restrict__ blk_off, const uint32_t *__restrict__ blk_seq,
-	uint4 *__restrict__ planes, uint32_t *__restrict__ nib, uint64_t total_blocks)
+	uint4 *__restrict__ planes, uint32_t *__restrict__ nib, uint32_t *__restrict__ tb, uint64_t total_blocks)
 {
 	const uint64_t gb = (uint64_t)blockIdx.x*blockDim.x + threadIdx.x;
 	if(gb >= total_blocks) return;
@@ -112,6 +113,7 @@ __global__ void k_transpose(const uint8_t *__restrict__ packed, const uint64_t *
 	const uint8_t *src = packed + byte_off[s];
 	uint32_t a = 0, c = 0, g = 0, t = 0;
 	uint32_t nw[4] = {0, 0, 0, 0};   // the same 32 codes, nibble j%8 of word j/8 (v2 scan's table index)
+	uint32_t tw[2] = {0, 0};
 	for(int j = 0;j < 32;++j){
 		const uint64_t pos = b*32 + j;
 		if(pos >= L) break;
@@ -122,9 +124,13 @@ __global__ void k_transpose(const uint8_t *__restrict__ packed, const uint64_t *
 		g |= ((code >> 2) & 1u) << j;
 		t |= ((code >> 3) & 1u) << j;
 		nw[j >> 3] |= code << ((j & 7)*4);
+		// 2-bit code for the seed scan: A,C,G,T -> 0..3; anything else (IUPAC, EOS) -> 0
+		const uint32_t c2 = (code == 2) ? 1u : (code == 4) ? 2u : (code == 8) ? 3u : 0u;
+		tw[j >> 4] |= c2 << ((j & 15)*2);
 	}
 	planes[gb] = make_uint4(a, c, g, t);
 	((uint4 *)nib)[gb] = make_uint4(nw[0], nw[1], nw[2], nw[3]);
+	((uint2 *)tb)[gb] = make_uint2(tw[0], tw[1]);
 }
 
 // One thread per block: validity of the 32 windows that START in it.  A window is regular iff
@@ -288,6 +294,7 @@ __global__ __launch_bounds__(IRR_THREADS) void k_scan_irr(const IrrDev *__restri
 }
 
 #include "pcr_scan_bitsliced.inc"
+#include "pcr_scan_seed.inc"
 
 // One workgroup per sequence: keep the hits that attain the final per-(sequence,candidate) maximum
 // (select_words.cpp:100-117), sort them by (loc, strand, kind, ord) (bitonic, LDS), drop duplicates
@@ -558,7 +565,8 @@ struct SeqSet {
 	uint64_t total_blocks = 0;
 	uint32_t n_tiles = 0, n_irr = 0;
 	DevBuf<uint4> planes;
-	DevBuf<uint32_t> valid, nib, blk_seq, tile_seq, tile_pos0, irr_off, seg_lo, seg_hi;
+	DevBuf<uint32_t> valid, nib, tb, blk_seq, tile_seq, tile_pos0, irr_off, seg_lo, seg_hi, degen_tiles;
+	DevBuf<uint8_t> tile_degen; uint32_t n_degen_tiles = 0;
 	DevBuf<uint64_t> d_len, d_blk_off, d_nblk_real;
 	DevBuf<uint8_t> d_active;
 	DevBuf<IrrDev> irr;
@@ -575,7 +583,7 @@ struct SeqSet {
 	uint32_t *d_seg_hi = nullptr;
 	void release()
 	{
-		planes.release(); valid.release(); nib.release(); blk_seq.release(); tile_seq.release(); tile_pos0.release();
+		planes.release(); valid.release(); nib.release(); tb.release(); degen_tiles.release(); tile_degen.release(); blk_seq.release(); tile_seq.release(); tile_pos0.release();
 		irr_off.release(); seg_lo.release(); seg_hi.release(); d_len.release(); d_blk_off.release();
 		d_nblk_real.release(); d_active.release(); irr.release(); db.release(); touched.release(); ctrl.release(); codes.release(); d_code_off.release();
 	}
@@ -593,7 +601,7 @@ struct pcr_ctx {
 	// scratch
 	DevBuf<uint4> cand_fwd, cand_rc;
 	DevBuf<uint32_t> cand_floor, best, counters, mask, status, tab, bias;
-	int scan_version = 2;
+	int scan_version = 3;
 	DevBuf<Hit> hits;
 	DevBuf<uint64_t> bits_fr, bits_rf;
 	DevBuf<OligoDev> oligos;
@@ -744,11 +752,12 @@ int amplify_launch(pcr_ctx *ctx, SeqSet &S, const pcr_pair *pairs, uint32_t n_pa
 }
 
 template<int NSLOT, int KLO>
-int launch_scan2_nw(pcr_ctx *ctx, SeqSet &S, uint32_t nw, uint32_t group0, uint32_t n_groups, uint32_t ncand, const HitSink &sink)
+int launch_scan2_nw(pcr_ctx *ctx, SeqSet &S, uint32_t nw, uint32_t group0, uint32_t n_groups, uint32_t ncand, const HitSink &sink,
+	const uint32_t *d_tab, const uint32_t *d_bias, const uint32_t *tile_ids, uint32_t n_tiles, const uint32_t *orient_ids)
 {
 #define SCAN2_ARGS S.nib.p, S.planes.p, S.valid.p, S.d_blk_off.p, S.d_len.p, S.d_active.p, S.tile_seq.p, S.tile_pos0.p, \
-	ctx->d_tab, ctx->d_bias, group0, ctx->d_cand_fwd, ctx->d_cand_rc, ctx->d_cand_floor, ncand, sink
-	const dim3 grid(S.n_tiles, n_groups), block(SCAN2_THREADS);
+	d_tab, d_bias, group0, tile_ids, orient_ids, ctx->d_cand_fwd, ctx->d_cand_rc, ctx->d_cand_floor, ncand, sink
+	const dim3 grid(n_tiles, n_groups), block(SCAN2_THREADS);
 	switch(nw){
 		case 1: hipLaunchKernelGGL((k_scan2<1, NSLOT, KLO>), grid, block, 0, ctx->stream, SCAN2_ARGS); break;
 		case 2: hipLaunchKernelGGL((k_scan2<2, NSLOT, KLO>), grid, block, 0, ctx->stream, SCAN2_ARGS); break;
@@ -766,17 +775,20 @@ int launch_scan2_nw(pcr_ctx *ctx, SeqSet &S, uint32_t nw, uint32_t group0, uint3
 
 // The bit-sliced scan over all orientation groups: full groups (8 words) in one launch, the
 // partial last group in a second one.
-int launch_scan2(pcr_ctx *ctx, SeqSet &S, const Scan2Tables &T, uint32_t ncand, const HitSink &sink)
+int launch_scan2(pcr_ctx *ctx, SeqSet &S, const Scan2Tables &T, uint32_t ncand, const HitSink &sink,
+	const uint32_t *d_tab, const uint32_t *d_bias, const uint32_t *tile_ids, uint32_t n_tiles, const uint32_t *orient_ids)
 {
+	if(n_tiles == 0 || T.n_groups == 0) return PCR_OK;
 	const uint32_t full = (T.last_words == 8) ? T.n_groups : T.n_groups - 1;
 	int rc = PCR_OK;
 	if(full){
-		rc = (T.nslot == 26) ? launch_scan2_nw<26, 3>(ctx, S, 8, 0, full, ncand, sink) : launch_scan2_nw<32, 0>(ctx, S, 8, 0, full, ncand, sink);
+		rc = (T.nslot == 26) ? launch_scan2_nw<26, 3>(ctx, S, 8, 0, full, ncand, sink, d_tab, d_bias, tile_ids, n_tiles, orient_ids)
+			: launch_scan2_nw<32, 0>(ctx, S, 8, 0, full, ncand, sink, d_tab, d_bias, tile_ids, n_tiles, orient_ids);
 		if(rc != PCR_OK) return rc;
 	}
 	if(full < T.n_groups){
-		rc = (T.nslot == 26) ? launch_scan2_nw<26, 3>(ctx, S, T.last_words, full, 1, ncand, sink)
-			: launch_scan2_nw<32, 0>(ctx, S, T.last_words, full, 1, ncand, sink);
+		rc = (T.nslot == 26) ? launch_scan2_nw<26, 3>(ctx, S, T.last_words, full, 1, ncand, sink, d_tab, d_bias, tile_ids, n_tiles, orient_ids)
+			: launch_scan2_nw<32, 0>(ctx, S, T.last_words, full, 1, ncand, sink, d_tab, d_bias, tile_ids, n_tiles, orient_ids);
 	}
 	return rc;
 }
@@ -827,7 +839,7 @@ pcr_ctx *pcr_create(int device, void *hip_stream, const pcr_params *params)
 	}
 	if(params){ ctx->params = *params; }
 	else{ ctx->params.pack_max_degen = 256; ctx->params.pack_min_gc = 0.0f; ctx->params.pack_max_gc = 1.0f; }
-	if(const char *v = getenv("PCRAMP_SCAN")){ if(v[0] == '1') ctx->scan_version = 1; }   // A/B: the v1 (per-orientation popcount) scan
+	if(const char *v = getenv("PCRAMP_SCAN")){ if(v[0] == '1') ctx->scan_version = 1; else if(v[0] == '2') ctx->scan_version = 2; }   // A/B: 1 = popcount scan, 2 = bit-sliced only
 	ctx->filt.max_degen = ctx->params.pack_max_degen;
 	ctx->filt.set_gc(ctx->params.pack_min_gc, ctx->params.pack_max_gc);
 	if(hipMemcpyToSymbol(HIP_SYMBOL(c_taq_mama), h_taq_mama, sizeof(h_taq_mama)) != hipSuccess ||
@@ -933,6 +945,9 @@ int pcr_load_sequences(pcr_ctx *ctx, pcr_set which, const uint8_t *packed4, cons
 	if((rc = S.planes.ensure(total_blocks)) != PCR_OK) return fail(rc);
 	if((rc = S.valid.ensure(total_blocks)) != PCR_OK) return fail(rc);
 	if((rc = S.nib.ensure(total_blocks*4 + 8)) != PCR_OK) return fail(rc);
+	if((rc = S.tb.ensure(total_blocks*2 + 8)) != PCR_OK) return fail(rc);
+	if((rc = S.tile_degen.ensure(n_tiles + 1)) != PCR_OK) return fail(rc);
+	if((rc = S.degen_tiles.ensure(n_tiles + 1)) != PCR_OK) return fail(rc);
 	if((rc = S.blk_seq.ensure(total_blocks)) != PCR_OK) return fail(rc);
 	if((rc = S.tile_seq.ensure(n_tiles)) != PCR_OK) return fail(rc);
 	if((rc = S.tile_pos0.ensure(n_tiles)) != PCR_OK) return fail(rc);
@@ -958,11 +973,27 @@ int pcr_load_sequences(pcr_ctx *ctx, pcr_set which, const uint8_t *packed4, cons
 		const unsigned threads = 256;
 		const unsigned grid = (unsigned)((total_blocks + threads - 1)/threads);
 		hipLaunchKernelGGL(k_transpose, dim3(grid), dim3(threads), 0, ctx->stream, d_packed.p, d_byte_off.p, S.d_len.p,
-			S.d_blk_off.p, S.blk_seq.p, S.planes.p, S.nib.p, total_blocks);
+			S.d_blk_off.p, S.blk_seq.p, S.planes.p, S.nib.p, S.tb.p, total_blocks);
 		if(hipGetLastError() != hipSuccess){ g_err = "k_transpose launch failed"; return fail(PCR_ERR_DEVICE); }
 		if((rc = run_valid(ctx, S, 0, total_blocks)) != PCR_OK) return fail(rc);
 	}
+	S.n_degen_tiles = 0;
+	if(n_tiles){
+		hipLaunchKernelGGL(k_tile_degen, dim3((unsigned)((n_tiles + 255)/256)), dim3(256), 0, ctx->stream, S.planes.p, S.d_blk_off.p,
+			S.d_nblk_real.p, S.tile_seq.p, S.tile_pos0.p, (uint32_t)n_tiles, S.tile_degen.p);
+		if(hipGetLastError() != hipSuccess){ g_err = "k_tile_degen launch failed"; return fail(PCR_ERR_DEVICE); }
+	}
 	if(hipStreamSynchronize(ctx->stream) != hipSuccess){ g_err = "load: stream sync failed"; return fail(PCR_ERR_DEVICE); }
+	if(n_tiles){
+		std::vector<uint8_t> flags(n_tiles);
+		std::vector<uint32_t> list;
+		if(hipMemcpy(flags.data(), S.tile_degen.p, n_tiles, hipMemcpyDeviceToHost) != hipSuccess){ g_err = "load: flag download failed"; return fail(PCR_ERR_DEVICE); }
+		for(uint64_t t2 = 0;t2 < n_tiles;++t2){ if(flags[t2]) list.push_back((uint32_t)t2); }
+		S.n_degen_tiles = (uint32_t)list.size();
+		if(!list.empty() && hipMemcpy(S.degen_tiles.p, list.data(), list.size()*sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess){
+			g_err = "load: tile list upload failed"; return fail(PCR_ERR_DEVICE);
+		}
+	}
 	d_packed.release(); d_byte_off.release();
 	return upload_irregular(ctx, S);
 }
@@ -1036,18 +1067,91 @@ int pcr_select_words(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_
 		HIP_TRY(hipMemsetAsync(ctx->best.p, 0, ctx->best.cap*sizeof(uint32_t), ctx->stream));
 		ctx->best_seen = ctx->best.p; ctx->epoch = 0;
 	}
-	Scan2Tables tables;
-	if(ctx->scan_version != 1) build_scan2_tables(cand, tables);
+	// ---- scan plan.  version 3 (default): orientations that can be seeded go through the pigeonhole seed
+	// scan; the others, and every tile holding IUPAC target codes, through the bit-sliced counter.
+	// version 2: bit-sliced counter for everything.  version 1: one popcount per (window, orientation).
+	const uint32_t n_or = 2*ncand;
+	std::vector<uint32_t> or_seed, or_plain;          // orientation ids
+	std::vector<pcrhost::Seed> seeds;
+	if(ctx->scan_version == 3 && n_or <= 65535){
+		for(uint32_t o = 0;o < n_or;++o){
+			const pcrhost::Candidate &c = cand[o >> 1];
+			if(pcrhost::orientation_seeds((o & 1) ? c.rc : c.fwd, c.floor_, o, seeds)) or_seed.push_back(o);
+			else or_plain.push_back(o);
+		}
+	}
+	else{ for(uint32_t o = 0;o < n_or;++o) or_plain.push_back(o); }
+	// seed tables per q (head: (start << 8) | count; a code with more than 255 seeds sends everything to the plain path)
+	std::vector<uint32_t> head[4], bitmap[4];
+	std::vector<SeedDev> seed_list;
+	uint32_t q_mask = 0;
+	if(!or_seed.empty()){
+		std::stable_sort(seeds.begin(), seeds.end(), [](const pcrhost::Seed &a, const pcrhost::Seed &b){
+			if(a.q != b.q) return a.q < b.q;
+			return a.code < b.code;
+		});
+		bool overflow = false;
+		for(size_t i = 0;i < seeds.size();){
+			size_t j = i;
+			while(j < seeds.size() && seeds[j].q == seeds[i].q && seeds[j].code == seeds[i].code) ++j;
+			const uint32_t qi = seeds[i].q - 5;
+			if(head[qi].empty()){ head[qi].assign(size_t(1) << (2*seeds[i].q), 0u); bitmap[qi].assign((size_t(1) << (2*seeds[i].q)) >> 5, 0u); q_mask |= 1u << qi; }
+			if(j - i > 255 || seed_list.size() >= (1u << 22)){ overflow = true; break; }
+			head[qi][seeds[i].code] = (j - i == 1) ? (SEED_SINGLE | ((uint32_t)seeds[i].orient << 8) | seeds[i].off)
+				: (((uint32_t)seed_list.size() << 8) | (uint32_t)(j - i));
+			bitmap[qi][seeds[i].code >> 5] |= 1u << (seeds[i].code & 31);
+			for(size_t k = i;k < j;++k){ SeedDev d; d.orient = seeds[k].orient; d.q = seeds[k].q; d.off = seeds[k].off; seed_list.push_back(d); }
+			i = j;
+		}
+		if(overflow){
+			or_plain.clear(); or_seed.clear(); seed_list.clear(); q_mask = 0;
+			for(uint32_t o = 0;o < n_or;++o) or_plain.push_back(o);
+		}
+	}
+	if(getenv("PCRAMP_DEBUG")) fprintf(stderr, "[pcramp] scan plan: %u candidates, %zu seeded orientations (%zu seeds), %zu plain, %u/%u IUPAC tiles\n",
+		ncand, or_seed.size(), seed_list.size(), or_plain.size(), S.n_degen_tiles, S.n_tiles);
+	Scan2Tables tab_plain, tab_seedset;               // bit-sliced tables: unseedable orientations (all tiles) / seedable ones (IUPAC tiles)
+	const bool need_plain = (ctx->scan_version != 1) && !or_plain.empty();
+	const bool need_seedset = !or_seed.empty() && S.n_degen_tiles > 0;
+	if(need_plain) build_scan2_tables(cand, or_plain, tab_plain);
+	if(need_seedset) build_scan2_tables(cand, or_seed, tab_seedset);
+	const uint32_t *d_tab_plain = nullptr, *d_bias_plain = nullptr, *d_map_plain = nullptr;
+	const uint32_t *d_tab_seedset = nullptr, *d_bias_seedset = nullptr, *d_map_seedset = nullptr;
+	SeedTables ST; memset(&ST, 0, sizeof(ST));
+	const SeedDev *d_seed_list = nullptr;
 	{
+		size_t bytes = ncand*(2*sizeof(uint4) + sizeof(uint32_t)) + 1024;
+		bytes += (tab_plain.tab.size() + tab_plain.bias.size() + or_plain.size() + 256)*sizeof(uint32_t);
+		bytes += (tab_seedset.tab.size() + tab_seedset.bias.size() + or_seed.size() + 256)*sizeof(uint32_t);
+		for(int q = 0;q < 4;++q) bytes += (head[q].size() + bitmap[q].size() + 8)*sizeof(uint32_t);
+		bytes += seed_list.size()*sizeof(SeedDev) + 64;
 		Stager st(ctx);
-		if((rc = st.begin(ncand*(2*sizeof(uint4) + sizeof(uint32_t)) + (tables.tab.size() + tables.bias.size())*sizeof(uint32_t) + 256)) != PCR_OK) return rc;
+		if((rc = st.begin(bytes)) != PCR_OK) return rc;
 		ctx->d_cand_fwd = st.put(hf.data(), ncand);
 		ctx->d_cand_rc = st.put(hr.data(), ncand);
 		ctx->d_cand_floor = st.put(hfl.data(), ncand);
-		if(ctx->scan_version != 1){
-			ctx->d_tab = st.put(tables.tab.data(), tables.tab.size());
-			ctx->d_bias = st.put(tables.bias.data(), tables.bias.size());
+		auto pad256 = [](std::vector<uint32_t> v){ v.resize((v.size() + 255) & ~size_t(255), 0xFFFFFFFFu); return v; };
+		if(need_plain){
+			d_tab_plain = st.put(tab_plain.tab.data(), tab_plain.tab.size());
+			d_bias_plain = st.put(tab_plain.bias.data(), tab_plain.bias.size());
+			const std::vector<uint32_t> m = pad256(or_plain);
+			d_map_plain = st.put(m.data(), m.size());
 		}
+		if(need_seedset){
+			d_tab_seedset = st.put(tab_seedset.tab.data(), tab_seedset.tab.size());
+			d_bias_seedset = st.put(tab_seedset.bias.data(), tab_seedset.bias.size());
+			const std::vector<uint32_t> m = pad256(or_seed);
+			d_map_seedset = st.put(m.data(), m.size());
+		}
+		uint32_t lds_words = 0;
+		for(int q = 0;q < 4;++q){
+			if(!((q_mask >> q) & 1u)) continue;
+			ST.head[q] = st.put(head[q].data(), head[q].size());
+			ST.bitmap[q] = st.put(bitmap[q].data(), bitmap[q].size());
+			ST.lds_off[q] = lds_words; lds_words += (uint32_t)bitmap[q].size();
+		}
+		ST.q_mask = q_mask; ST.lds_words = lds_words;
+		if(!seed_list.empty()) d_seed_list = st.put(seed_list.data(), seed_list.size());
 		if((rc = st.ship()) != PCR_OK) return rc;
 	}
 
@@ -1081,7 +1185,15 @@ int pcr_select_words(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_
 				HIP_TRY(hipGetLastError());
 			}
 			else{
-				if((rc = launch_scan2(ctx, S, tables, ncand, sink)) != PCR_OK) return rc;
+				if(need_plain && (rc = launch_scan2(ctx, S, tab_plain, ncand, sink, d_tab_plain, d_bias_plain, nullptr, S.n_tiles, d_map_plain)) != PCR_OK) return rc;
+				if(!or_seed.empty()){
+					hipLaunchKernelGGL(k_seed, dim3((S.n_tiles + SEED_TILES_PER_WG - 1)/SEED_TILES_PER_WG), dim3(SEED_THREADS), ST.lds_words*sizeof(uint32_t),
+						ctx->stream, S.tb.p, S.planes.p, S.valid.p, S.d_blk_off.p, S.d_len.p, S.d_active.p, S.tile_seq.p, S.tile_pos0.p,
+						S.tile_degen.p, S.n_tiles, ST, d_seed_list, ctx->d_cand_fwd, ctx->d_cand_rc, ctx->d_cand_floor, sink);
+					HIP_TRY(hipGetLastError());
+					if(need_seedset && (rc = launch_scan2(ctx, S, tab_seedset, ncand, sink, d_tab_seedset, d_bias_seedset, S.degen_tiles.p,
+						S.n_degen_tiles, d_map_seedset)) != PCR_OK) return rc;
+				}
 			}
 			if(ctx->prof){
 				HIP_TRY(hipEventRecord(e1, ctx->stream));

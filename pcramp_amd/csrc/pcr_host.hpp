@@ -455,5 +455,71 @@ inline double planes_degeneracy(const Planes &w)
 	return r;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Pigeonhole seeds for the match scan.
+//
+// An orientation with m occupied slots and floor f tolerates k = m - f mismatching slots.  Cut
+// the occupied slots into k+1 disjoint blocks: a window reaching the floor matches at least one
+// block in every slot.  So it is enough to examine the windows where some block matches exactly
+// -- found by looking up the TARGET's q-gram (2 bits per base) at the block's offset in a table
+// of seed codes -- and to evaluate only those windows exactly.  An oligo slot with an IUPAC set
+// contributes one seed code per member base (bounded); a target q-gram holding an IUPAC code can
+// match seeds it is not equal to, so tiles containing such bases are scanned by the bit-sliced
+// kernel instead (pcr_device.hip).  Orientations whose blocks would be shorter than MIN_SEED_Q
+// (low thresholds) are "unseedable" and also go to the bit-sliced kernel.
+struct Seed { uint32_t code; uint16_t orient; uint8_t q; uint8_t off; };   // orient = 2*candidate + {0: fwd, 1: rc}; off = slot of the seed's first base
+
+enum { MIN_SEED_Q = 5, MAX_SEED_Q = 8, MAX_SEED_EXPANSION = 16 };
+
+// Appends the seeds of one orientation; returns false (nothing appended) if it cannot be seeded.
+inline bool orientation_seeds(const Planes &m, uint32_t floor_, uint32_t orient, std::vector<Seed> &out)
+{
+	const int size = planes_size(m);
+	if(size == 0 || floor_ == 0 || floor_ > (uint32_t)size) return floor_ > (uint32_t)size;   // dead orientation: trivially "seeded" with no seeds
+	const int k = size - (int)floor_;
+	const int nblk = k + 1;
+	if(size/nblk < MIN_SEED_Q) return false;
+	// occupied slots in order (oligos are contiguous, but do not rely on it)
+	int slots[32], n = 0;
+	for(int s = 0;s < 32;++s){ if(planes_nibble(m, s)) slots[n++] = s; }
+	for(int s = 1;s < n;++s){ if(slots[s] != slots[s - 1] + 1) return false; }       // holes: leave it to the bit-sliced scan
+	const size_t first_out = out.size();
+	int pos = 0;
+	for(int b = 0;b < nblk;++b){
+		const int len = size/nblk + ((b < size % nblk) ? 1 : 0);
+		const int q = std::min<int>(len, MAX_SEED_Q);
+		// the q-subwindow of the block with the fewest expansions
+		int best_w = -1; unsigned best_e = ~0u;
+		for(int w = 0;w + q <= len;++w){
+			unsigned e = 1;
+			for(int j = 0;j < q;++j) e *= (unsigned)__builtin_popcount(planes_nibble(m, slots[pos + w + j]));
+			if(e < best_e){ best_e = e; best_w = w; }
+		}
+		if(best_e > MAX_SEED_EXPANSION){ out.resize(first_out); return false; }
+		// enumerate the member codes (A=0,C=1,G=2,T=3; first base in the LOW bits)
+		unsigned idx[MAX_SEED_Q]; for(int j = 0;j < q;++j) idx[j] = 0;
+		while(true){
+			uint32_t code = 0; bool ok = true;
+			for(int j = 0;j < q;++j){
+				const unsigned set = planes_nibble(m, slots[pos + best_w + j]);
+				unsigned seen = 0, base = 4;
+				for(unsigned bb = 0;bb < 4;++bb){ if(set & (1u << bb)){ if(seen == idx[j]){ base = bb; break; } ++seen; } }
+				if(base == 4){ ok = false; break; }
+				code |= base << (2*j);
+			}
+			if(ok){ Seed sd; sd.code = code; sd.orient = (uint16_t)orient; sd.q = (uint8_t)q; sd.off = (uint8_t)slots[pos + best_w]; out.push_back(sd); }
+			int j = 0;
+			for(;j < q;++j){
+				const unsigned cnt = (unsigned)__builtin_popcount(planes_nibble(m, slots[pos + best_w + j]));
+				if(++idx[j] < cnt) break;
+				idx[j] = 0;
+			}
+			if(j == q) break;
+		}
+		pos += len;
+	}
+	return true;
+}
+
 } // namespace pcrhost
 #endif
