@@ -195,8 +195,10 @@ __global__ void k_valid(const uint4 *__restrict__ planes, const uint64_t *__rest
 // Hits are appended to a fixed-capacity bucket per sequence (`cap` slots each), so the arg-max
 // filter, the dedupe and the ordering by WordMatch::loc can be done per sequence by one workgroup
 // (k_finalize) with no global sort.  counters[0]: overflow flag, counters[2]: largest bucket fill seen.
-struct HitSink { uint32_t *best; Hit *hits; uint32_t *seq_count; uint32_t *counters; uint32_t *touched; uint32_t cap; uint32_t ncand; uint32_t epoch; };
-// counters[3] / touched[]: the sequences that received at least one hit, in arrival order.
+struct HitSink { uint32_t *best; Hit *hits; uint32_t *seq_count; uint32_t *counters; uint32_t cap; uint32_t ncand; uint32_t epoch; };
+// counters[3] / touched[]: the sequences that received at least one hit, listed by k_touched after the scans
+// (one wave-aggregated atomic per 64 sequences: appending from record_hit cost ~35 ns per touched sequence,
+// all on one address -- more than the whole seed scan).
 // best[] holds (pass epoch << 8) | count, so it never needs clearing: values of earlier passes compare lower.
 
 __device__ __noinline__ void record_hit(const HitSink &k, uint32_t seq, uint32_t cand, uint64_t key, uint32_t cnt)
@@ -205,7 +207,6 @@ __device__ __noinline__ void record_hit(const HitSink &k, uint32_t seq, uint32_t
 	const uint32_t old = atomicMax(&k.best[(size_t)seq*k.ncand + cand], tagged);
 	if(tagged >= old){
 		const uint32_t slot = atomicAdd(&k.seq_count[seq], 1u);
-		if(slot == 0) k.touched[atomicAdd(&k.counters[3], 1u)] = seq;
 		if(slot < k.cap){
 			Hit h; h.key = key; h.cand = cand; h.cnt = cnt;
 			k.hits[(size_t)seq*k.cap + slot] = h;
@@ -218,6 +219,19 @@ __device__ __forceinline__ uint64_t make_key(uint32_t seq, int32_t loc, uint32_t
 {
 	return ((uint64_t)seq << KEY_SEQ_SHIFT) | ((uint64_t)(uint32_t)(loc + LOC_BIAS) << KEY_LOC_SHIFT) |
 		((uint64_t)(strand - 1) << 7) | ((uint64_t)kind << 6) | ord;
+}
+
+__global__ void k_touched(const uint32_t *__restrict__ seq_count, uint32_t n, uint32_t *__restrict__ counters, uint32_t *__restrict__ touched)
+{
+	const uint32_t s = blockIdx.x*blockDim.x + threadIdx.x;
+	const bool has = s < n && seq_count[s] > 0;
+	const uint64_t mask = __ballot(has);
+	if(!mask) return;
+	const uint32_t lane = threadIdx.x & 63u, leader = (uint32_t)__builtin_ctzll(mask);
+	uint32_t base = 0;
+	if(lane == leader) base = atomicAdd(&counters[3], (uint32_t)__builtin_popcountll(mask));
+	base = __shfl(base, leader);
+	if(has) touched[base + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull))] = s;
 }
 
 // v1 match scan: one lane = one window start; the window's four 32-bit plane slices live in
@@ -577,7 +591,7 @@ struct SeqSet {
 	uint32_t db_cap = 0;        // slots per sequence in `db`; the entries of sequence s are db[s*db_cap .. seg_hi[s])
 	uint64_t n_slots = 0;       // n * db_cap
 	DevBuf<DevEntry> db;
-	DevBuf<uint32_t> touched;     // sequences holding DB entries (arrival order)
+	DevBuf<uint32_t> touched;     // sequences holding DB entries (k_touched)
 	DevBuf<uint32_t> ctrl;        // [0..7] counters | [8, 8+n) per-sequence hit counts | [8+n, 8+2n) seg_hi : one memset per pass
 	uint32_t n_touched = 0;
 	uint32_t *d_seg_hi = nullptr;
@@ -1081,35 +1095,63 @@ int pcr_select_words(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_
 		}
 	}
 	else{ for(uint32_t o = 0;o < n_or;++o) or_plain.push_back(o); }
-	// seed tables per q (head: (start << 8) | count; a code with more than 255 seeds sends everything to the plain path)
-	std::vector<uint32_t> head[4], bitmap[4];
-	std::vector<SeedDev> seed_list;
-	uint32_t q_mask = 0;
+	// LDS image of the seed scan (layout: pcr_scan_seed.inc).  Too many distinct codes, or a code shared by
+	// more than 255 seeds, sends everything to the bit-sliced path.
+	std::vector<uint32_t> image;
+	SeedTables ST; memset(&ST, 0, sizeof(ST));
+	size_t n_seeds = seeds.size();
 	if(!or_seed.empty()){
 		std::stable_sort(seeds.begin(), seeds.end(), [](const pcrhost::Seed &a, const pcrhost::Seed &b){
 			if(a.q != b.q) return a.q < b.q;
 			return a.code < b.code;
 		});
+		uint32_t q_mask = 0;
+		for(const pcrhost::Seed &sd : seeds) q_mask |= 1u << (sd.q - 5);
+		uint32_t words = 0;
+		for(int q = 0;q < 4;++q){
+			if(!((q_mask >> q) & 1u)) continue;
+			const uint32_t w = (1u << (2*(q + 5))) >> 5;
+			ST.bm_off[q] = words; words += w;
+			ST.rank_off[q] = words; words += w;
+		}
+		image.assign(words, 0u);
+		std::vector<uint32_t> heads, multi;
 		bool overflow = false;
 		for(size_t i = 0;i < seeds.size();){
 			size_t j = i;
 			while(j < seeds.size() && seeds[j].q == seeds[i].q && seeds[j].code == seeds[i].code) ++j;
 			const uint32_t qi = seeds[i].q - 5;
-			if(head[qi].empty()){ head[qi].assign(size_t(1) << (2*seeds[i].q), 0u); bitmap[qi].assign((size_t(1) << (2*seeds[i].q)) >> 5, 0u); q_mask |= 1u << qi; }
-			if(j - i > 255 || seed_list.size() >= (1u << 22)){ overflow = true; break; }
-			head[qi][seeds[i].code] = (j - i == 1) ? (SEED_SINGLE | ((uint32_t)seeds[i].orient << 8) | seeds[i].off)
-				: (((uint32_t)seed_list.size() << 8) | (uint32_t)(j - i));
-			bitmap[qi][seeds[i].code >> 5] |= 1u << (seeds[i].code & 31);
-			for(size_t k = i;k < j;++k){ SeedDev d; d.orient = seeds[k].orient; d.q = seeds[k].q; d.off = seeds[k].off; seed_list.push_back(d); }
+			if(j - i > 255 || heads.size() >= SEED_MAX_CODES){ overflow = true; break; }
+			image[ST.bm_off[qi] + (seeds[i].code >> 5)] |= 1u << (seeds[i].code & 31);
+			if(j - i == 1) heads.push_back(SEED_SINGLE | ((uint32_t)seeds[i].orient << 8) | seeds[i].off);
+			else{
+				heads.push_back(((uint32_t)multi.size() << 8) | (uint32_t)(j - i));
+				for(size_t k = i;k < j;++k) multi.push_back((uint32_t)seeds[k].orient | ((uint32_t)seeds[k].q << 16) | ((uint32_t)seeds[k].off << 24));
+			}
 			i = j;
 		}
+		// workgroup LDS budget: 64 KB, of which SeedShared takes ~6 KB
+		const size_t cand_bytes = (ncand <= SEED_CAND_LDS) ? (size_t)ncand*(2*sizeof(uint4) + sizeof(uint32_t)) : 0;
+		if(!overflow && (image.size() + heads.size() + multi.size() + 4)*sizeof(uint32_t) + cand_bytes > 48*1024) overflow = true;
 		if(overflow){
-			or_plain.clear(); or_seed.clear(); seed_list.clear(); q_mask = 0;
+			or_plain.clear(); or_seed.clear(); image.clear();
 			for(uint32_t o = 0;o < n_or;++o) or_plain.push_back(o);
+		}
+		else{
+			// rank: heads[] is in (q, code) order, so the running bit count is the index
+			uint32_t run = 0;
+			for(int q = 0;q < 4;++q){
+				if(!((q_mask >> q) & 1u)) continue;
+				const uint32_t w = (1u << (2*(q + 5))) >> 5;
+				for(uint32_t k = 0;k < w;++k){ image[ST.rank_off[q] + k] = run; run += (uint32_t)__builtin_popcount(image[ST.bm_off[q] + k]); }
+			}
+			ST.heads_off = (uint32_t)image.size(); image.insert(image.end(), heads.begin(), heads.end());
+			ST.multi_off = (uint32_t)image.size(); image.insert(image.end(), multi.begin(), multi.end());
+			ST.q_mask = q_mask; ST.lds_words = (uint32_t)image.size();
 		}
 	}
 	if(getenv("PCRAMP_DEBUG")) fprintf(stderr, "[pcramp] scan plan: %u candidates, %zu seeded orientations (%zu seeds), %zu plain, %u/%u IUPAC tiles\n",
-		ncand, or_seed.size(), seed_list.size(), or_plain.size(), S.n_degen_tiles, S.n_tiles);
+		ncand, or_seed.size(), n_seeds, or_plain.size(), S.n_degen_tiles, S.n_tiles);
 	Scan2Tables tab_plain, tab_seedset;               // bit-sliced tables: unseedable orientations (all tiles) / seedable ones (IUPAC tiles)
 	const bool need_plain = (ctx->scan_version != 1) && !or_plain.empty();
 	const bool need_seedset = !or_seed.empty() && S.n_degen_tiles > 0;
@@ -1117,14 +1159,11 @@ int pcr_select_words(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_
 	if(need_seedset) build_scan2_tables(cand, or_seed, tab_seedset);
 	const uint32_t *d_tab_plain = nullptr, *d_bias_plain = nullptr, *d_map_plain = nullptr;
 	const uint32_t *d_tab_seedset = nullptr, *d_bias_seedset = nullptr, *d_map_seedset = nullptr;
-	SeedTables ST; memset(&ST, 0, sizeof(ST));
-	const SeedDev *d_seed_list = nullptr;
 	{
 		size_t bytes = ncand*(2*sizeof(uint4) + sizeof(uint32_t)) + 1024;
 		bytes += (tab_plain.tab.size() + tab_plain.bias.size() + or_plain.size() + 256)*sizeof(uint32_t);
 		bytes += (tab_seedset.tab.size() + tab_seedset.bias.size() + or_seed.size() + 256)*sizeof(uint32_t);
-		for(int q = 0;q < 4;++q) bytes += (head[q].size() + bitmap[q].size() + 8)*sizeof(uint32_t);
-		bytes += seed_list.size()*sizeof(SeedDev) + 64;
+		bytes += (image.size() + 64)*sizeof(uint32_t);
 		Stager st(ctx);
 		if((rc = st.begin(bytes)) != PCR_OK) return rc;
 		ctx->d_cand_fwd = st.put(hf.data(), ncand);
@@ -1143,15 +1182,7 @@ int pcr_select_words(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_
 			const std::vector<uint32_t> m = pad256(or_seed);
 			d_map_seedset = st.put(m.data(), m.size());
 		}
-		uint32_t lds_words = 0;
-		for(int q = 0;q < 4;++q){
-			if(!((q_mask >> q) & 1u)) continue;
-			ST.head[q] = st.put(head[q].data(), head[q].size());
-			ST.bitmap[q] = st.put(bitmap[q].data(), bitmap[q].size());
-			ST.lds_off[q] = lds_words; lds_words += (uint32_t)bitmap[q].size();
-		}
-		ST.q_mask = q_mask; ST.lds_words = lds_words;
-		if(!seed_list.empty()) d_seed_list = st.put(seed_list.data(), seed_list.size());
+		if(!image.empty()) ST.image = st.put(image.data(), image.size());
 		if((rc = st.ship()) != PCR_OK) return rc;
 	}
 
@@ -1171,7 +1202,7 @@ int pcr_select_words(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_
 		HIP_TRY(hipMemsetAsync(S.ctrl.p, 0, (8 + 2*(size_t)S.n)*sizeof(uint32_t), ctx->stream));
 		++ctx->epoch;
 		HitSink sink; sink.best = ctx->best.p; sink.hits = ctx->hits.p; sink.seq_count = d_seq_count;
-		sink.counters = d_counters; sink.touched = S.touched.p; sink.cap = cap; sink.ncand = ncand; sink.epoch = ctx->epoch;
+		sink.counters = d_counters; sink.cap = cap; sink.ncand = ncand; sink.epoch = ctx->epoch;
 		if(S.n_tiles){
 			hipEvent_t e0 = nullptr, e1 = nullptr;
 			if(ctx->prof){
@@ -1187,9 +1218,14 @@ int pcr_select_words(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_
 			else{
 				if(need_plain && (rc = launch_scan2(ctx, S, tab_plain, ncand, sink, d_tab_plain, d_bias_plain, nullptr, S.n_tiles, d_map_plain)) != PCR_OK) return rc;
 				if(!or_seed.empty()){
-					hipLaunchKernelGGL(k_seed, dim3((S.n_tiles + SEED_TILES_PER_WG - 1)/SEED_TILES_PER_WG), dim3(SEED_THREADS), ST.lds_words*sizeof(uint32_t),
-						ctx->stream, S.tb.p, S.planes.p, S.valid.p, S.d_blk_off.p, S.d_len.p, S.d_active.p, S.tile_seq.p, S.tile_pos0.p,
-						S.tile_degen.p, S.n_tiles, ST, d_seed_list, ctx->d_cand_fwd, ctx->d_cand_rc, ctx->d_cand_floor, sink);
+					const bool cand_lds = ncand <= SEED_CAND_LDS;
+					const size_t dyn = (size_t)((ST.lds_words + 3u) & ~3u)*sizeof(uint32_t) + (cand_lds ? (size_t)ncand*(2*sizeof(uint4) + sizeof(uint32_t)) : 0);
+					const dim3 sgrid((S.n_tiles + SEED_TILES_PER_WG - 1)/SEED_TILES_PER_WG), sblock(SEED_THREADS);
+#define SEED_ARGS S.tb.p, S.planes.p, S.valid.p, S.d_blk_off.p, S.d_nblk_real.p, S.d_len.p, S.d_active.p, S.tile_seq.p, S.tile_pos0.p, \
+	S.tile_degen.p, S.n_tiles, ST, ctx->d_cand_fwd, ctx->d_cand_rc, ctx->d_cand_floor, ncand, sink
+					if(cand_lds) hipLaunchKernelGGL(k_seed<true>, sgrid, sblock, dyn, ctx->stream, SEED_ARGS);
+					else hipLaunchKernelGGL(k_seed<false>, sgrid, sblock, dyn, ctx->stream, SEED_ARGS);
+#undef SEED_ARGS
 					HIP_TRY(hipGetLastError());
 					if(need_seedset && (rc = launch_scan2(ctx, S, tab_seedset, ncand, sink, d_tab_seedset, d_bias_seedset, S.degen_tiles.p,
 						S.n_degen_tiles, d_map_seedset)) != PCR_OK) return rc;
@@ -1206,6 +1242,8 @@ int pcr_select_words(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_
 				S.n_irr, S.d_active.p, min_oligo_length, ctx->d_cand_fwd, ctx->d_cand_floor, ncand, sink);
 			HIP_TRY(hipGetLastError());
 		}
+		hipLaunchKernelGGL(k_touched, dim3((S.n + 255)/256), dim3(256), 0, ctx->stream, d_seq_count, S.n, d_counters, S.touched.p);
+		HIP_TRY(hipGetLastError());
 		uint32_t np2 = 1; while(np2 < cap) np2 <<= 1;
 		hipLaunchKernelGGL(k_finalize, dim3((S.n + FIN_WAVES - 1)/FIN_WAVES), dim3(FIN_THREADS), (size_t)FIN_WAVES*np2*sizeof(uint64_t), ctx->stream,
 			ctx->hits.p, d_seq_count, cap, ctx->best.p, ncand, S.planes.p, S.d_blk_off.p, S.irr.p, S.irr_off.p, S.db.p, S.d_seg_hi,
