@@ -235,6 +235,16 @@ int pcr_host_window_valid(const uint8_t *packed4, uint64_t len, const pcr_params
 int64_t pcr_host_candidates(const pcr_pair *pairs, uint32_t n_pairs, int optimize_5, int optimize_3,
 	float threshold, pcr_word128 *words_out, uint32_t *floors_out, uint64_t cap);
 
+/* The seed scan's filter for one candidate orientation (host model of what pcr_select_words
+ * uploads; no reference counterpart -- the reference counts every window, select_words.cpp:100-117).
+ * `oligo` is matched as given against 32-base windows (slot k of the word <-> base k of the
+ * window); a window reaches `floor` matching slots only if, for some returned seed i, its bases
+ * off[i] .. off[i]+q[i]-1 spell codes[i] (2 bits per base, A,C,G,T = 0..3, first base in the low
+ * bits).  Returns the seed count (may exceed cap), or -1 if the orientation cannot be seeded
+ * (the bit-sliced scan handles it). */
+int64_t pcr_host_orientation_seeds(const pcr_word128 *oligo, uint32_t floor, uint32_t *codes, uint8_t *q,
+	uint8_t *off, uint64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -77,6 +77,7 @@ ABI_SYMBOLS = [
     "pcr_select_words", "pcr_get_entries", "pcr_amplify", "pcr_amplify_device", "pcr_coverage_from_bits",
     "pcr_weighted_coverage", "pcr_num_sequences", "pcr_bitset_words", "pcr_profile_enable", "pcr_profile_read",
     "pcr_synchronize", "pcr_host_irregular_words", "pcr_host_window_valid", "pcr_host_candidates",
+    "pcr_host_orientation_seeds",
     "pcr_sw_align_words", "pcr_background_match", "pcr_multiplex_match",
     "pcr_thermo", "pcr_dimer", "pcr_multiplex_compatible",
 ]
@@ -129,6 +130,8 @@ def load_library():
     L.pcr_host_window_valid.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(_Params), C.c_void_p]
     L.pcr_host_candidates.restype = C.c_int64
     L.pcr_host_candidates.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_uint64]
+    L.pcr_host_orientation_seeds.restype = C.c_int64
+    L.pcr_host_orientation_seeds.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
     _LIB = L
     return L
 
@@ -158,6 +161,20 @@ def host_window_valid(packed, length, pack_max_degen=256, pack_min_gc=0.0, pack_
     if L.pcr_host_window_valid(buf.ctypes.data, length, C.byref(p), out.ctypes.data) != 0:
         raise PcrError(_err(L))
     return out[:length]
+
+
+def host_orientation_seeds(word, floor):
+    """Seeds (code, q, off) of one oligo word as the seed scan would use them, or None if unseedable."""
+    L = load_library()
+    w = np.array([int(word[0]), int(word[1])], dtype=np.uint64)
+    n = L.pcr_host_orientation_seeds(w.ctypes.data, int(floor), None, None, None, 0)
+    if n < 0:
+        return None
+    codes = np.zeros(max(int(n), 1), np.uint32)
+    q = np.zeros(max(int(n), 1), np.uint8)
+    off = np.zeros(max(int(n), 1), np.uint8)
+    L.pcr_host_orientation_seeds(w.ctypes.data, int(floor), codes.ctypes.data, q.ctypes.data, off.ctypes.data, n)
+    return [(int(codes[i]), int(q[i]), int(off[i])) for i in range(int(n))]
 
 
 def host_candidates(pairs, optimize_5=False, optimize_3=False, threshold=0.9):

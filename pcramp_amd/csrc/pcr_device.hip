@@ -282,26 +282,36 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(
 	}
 }
 
-// Irregular words: one lane per word; the candidate masks are staged through LDS in chunks.
-constexpr int IRR_THREADS = 256, IRR_CHUNK = 512;
-__global__ __launch_bounds__(IRR_THREADS) void k_scan_irr(const IrrDev *__restrict__ irr, uint32_t n_irr, const uint8_t *__restrict__ active,
-	uint32_t min_len, const uint4 *__restrict__ cand_fwd, const uint32_t *__restrict__ cand_floor, uint32_t ncand,
+// Irregular words: every lane keeps IRR_PER_LANE words in registers; the candidates are walked in the
+// outer loop, so their planes and floors are wave-uniform (scalar loads, SGPR operands): 4 and/or +
+// popcount + compare per (word, candidate).  grid.x = ceil(n_live / (IRR_THREADS*IRR_PER_LANE)).
+constexpr int IRR_THREADS = 256, IRR_PER_LANE = 2;
+__global__ __launch_bounds__(IRR_THREADS) void k_scan_irr(const IrrDev *__restrict__ irr, const uint32_t *__restrict__ perm, uint32_t n_live,
+	const uint8_t *__restrict__ active, const uint4 *__restrict__ cand_fwd, const uint32_t *__restrict__ cand_floor, uint32_t ncand,
 	HitSink sink)
 {
-	__shared__ uint4 c_m[IRR_CHUNK];
-	__shared__ uint32_t c_f[IRR_CHUNK];
-	for(uint32_t c0 = 0;c0 < ncand;c0 += IRR_CHUNK){
-		const uint32_t nc = min((uint32_t)IRR_CHUNK, ncand - c0);
-		__syncthreads();
-		for(uint32_t c = threadIdx.x;c < nc;c += IRR_THREADS){ c_m[c] = cand_fwd[c0 + c]; c_f[c] = cand_floor[c0 + c]; }
-		__syncthreads();
-		for(uint32_t i = blockIdx.x*IRR_THREADS + threadIdx.x;i < n_irr;i += gridDim.x*IRR_THREADS){
-			const IrrDev e = irr[i];
-			if(!active[e.seq] || (((e.meta >> 8) & 0xFF) < min_len)) continue;           // sequence.cpp:157,239
-			const uint64_t key = make_key(e.seq, e.loc, e.meta & 0xFF, 1, (e.meta >> 16) & 0xFF);
-			for(uint32_t c = 0;c < nc;++c){
-				const uint32_t cnt = match_count(e.w.a, e.w.c, e.w.g, e.w.t, c_m[c]);
-				if(cnt >= c_f[c]) record_hit(sink, e.seq, c0 + c, key, cnt);
+	uint32_t wa[IRR_PER_LANE], wc[IRR_PER_LANE], wg[IRR_PER_LANE], wt[IRR_PER_LANE];
+	const uint32_t i0 = blockIdx.x*(IRR_THREADS*IRR_PER_LANE) + threadIdx.x;
+#pragma unroll
+	for(int k = 0;k < IRR_PER_LANE;++k){
+		const uint32_t i = i0 + k*IRR_THREADS;
+		wa[k] = wc[k] = wg[k] = wt[k] = 0;               // an empty word matches nothing (floors are >= 1 here, see below)
+		if(i < n_live){                                  // the words whose size counter reaches min_oligo_length (sequence.cpp:157,239)
+			const IrrDev e = irr[perm[i]];
+			if(active[e.seq]){ wa[k] = e.w.a; wc[k] = e.w.c; wg[k] = e.w.g; wt[k] = e.w.t; }
+		}
+	}
+#pragma unroll 8
+	for(uint32_t c = 0;c < ncand;++c){
+		const uint4 m = cand_fwd[c];
+		const uint32_t fl = max(cand_floor[c], 1u);      // floor 0 ("everything matches") still needs one matching slot to exist as a word
+		const bool zero_floor = cand_floor[c] == 0;
+#pragma unroll
+		for(int k = 0;k < IRR_PER_LANE;++k){
+			const uint32_t cnt = match_count(wa[k], wc[k], wg[k], wt[k], m);
+			if(cnt >= fl || (zero_floor && (wa[k] | wc[k] | wg[k] | wt[k]))){
+				const IrrDev e = irr[perm[i0 + k*IRR_THREADS]];
+				record_hit(sink, e.seq, c, make_key(e.seq, e.loc, e.meta & 0xFF, 1, (e.meta >> 16) & 0xFF), cnt);
 			}
 		}
 	}
@@ -314,7 +324,8 @@ __global__ __launch_bounds__(IRR_THREADS) void k_scan_irr(const IrrDev *__restri
 // (select_words.cpp:100-117), sort them by (loc, strand, kind, ord) (bitonic, LDS), drop duplicates
 // (the union over candidates, select_words.cpp:126-128) and materialise the DB entries of the
 // sequence into its slot range [seq*cap, seq*cap + n).  seg_hi[seq] = seq*cap + n.
-constexpr int FIN_WAVES = 8, FIN_THREADS = 64*FIN_WAVES;   // one wave per sequence, 8 sequences per workgroup
+constexpr int FIN_WAVES = 8;          // one wave per sequence, 8 sequences per workgroup (1 when the buckets outgrow 1024 hits: LDS)
+constexpr uint32_t MAX_BUCKET_CAP = 8192;   // 8192 keys x 8 B = the 64 KB of LDS one wave may sort in
 
 // LDS hand-off between lanes of ONE wave: order the wave's own LDS traffic, no workgroup barrier
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
@@ -347,16 +358,17 @@ __device__ void materialise_entry(uint64_t k, const uint4 *__restrict__ planes, 
 	}
 }
 
-__global__ __launch_bounds__(FIN_THREADS) void k_finalize(const Hit *__restrict__ hits, const uint32_t *__restrict__ seq_count,
+template<int WAVES>
+__global__ __launch_bounds__(64*WAVES) void k_finalize(const Hit *__restrict__ hits, const uint32_t *__restrict__ seq_count,
 	uint32_t cap, const uint32_t *__restrict__ best, uint32_t ncand, const uint4 *__restrict__ planes,
 	const uint64_t *__restrict__ blk_off, const IrrDev *__restrict__ irr, const uint32_t *__restrict__ irr_off,
 	DevEntry *__restrict__ db, uint32_t *__restrict__ seg_hi, uint32_t *__restrict__ counters, uint32_t epoch,
 	const uint32_t *__restrict__ touched)
 {
-	extern __shared__ __attribute__((aligned(16))) uint64_t fin_lds[];   // FIN_WAVES x np2cap keys
-	__shared__ uint32_t part_all[FIN_THREADS];
+	extern __shared__ __attribute__((aligned(16))) uint64_t fin_lds[];   // WAVES x np2cap keys
+	__shared__ uint32_t part_all[64*WAVES];
 	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	const uint32_t t_idx = blockIdx.x*FIN_WAVES + wave;
+	const uint32_t t_idx = blockIdx.x*WAVES + wave;
 	if(t_idx >= counters[3]) return;            // only sequences that received hits (seg_hi of the others stays 0 = empty)
 	const uint32_t seq = touched[t_idx];
 	uint32_t np2cap = 1; while(np2cap < cap) np2cap <<= 1;
@@ -414,6 +426,73 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(const Hit *__restrict_
 	}
 }
 
+// Buckets beyond MAX_BUCKET_CAP (low-complexity sequence against low-complexity oligos: thousands of tied
+// windows): the same filter / sort / dedupe / materialise with the keys in global scratch and one
+// 256-thread workgroup per touched sequence.  Slow path; exists so that such inputs are not refused.
+constexpr int FINBIG_THREADS = 256;
+constexpr uint32_t MAX_BUCKET_CAP_GLOBAL = 65536;
+__global__ __launch_bounds__(FINBIG_THREADS) void k_finalize_big(const Hit *__restrict__ hits, const uint32_t *__restrict__ seq_count,
+	uint32_t cap, const uint32_t *__restrict__ best, uint32_t ncand, const uint4 *__restrict__ planes,
+	const uint64_t *__restrict__ blk_off, const IrrDev *__restrict__ irr, const uint32_t *__restrict__ irr_off,
+	DevEntry *__restrict__ db, uint32_t *__restrict__ seg_hi, uint32_t *__restrict__ counters, uint32_t epoch,
+	const uint32_t *__restrict__ touched, uint64_t *__restrict__ scratch)
+{
+	__shared__ uint32_t part[FINBIG_THREADS];
+	if(blockIdx.x >= counters[3]) return;
+	const uint32_t seq = touched[blockIdx.x], tid = threadIdx.x;
+	uint32_t np2cap = 1; while(np2cap < cap) np2cap <<= 1;
+	uint64_t *fin_keys = scratch + (size_t)blockIdx.x*np2cap;
+	const uint32_t n = min(seq_count[seq], cap);
+	uint32_t np2 = 1; while(np2 < n) np2 <<= 1;
+	for(uint32_t i = tid;i < np2;i += FINBIG_THREADS){
+		uint64_t k = ~0ull;
+		if(i < n){
+			const Hit h = hits[(size_t)seq*cap + i];
+			if(((epoch << 8) | h.cnt) == best[(size_t)seq*ncand + h.cand]) k = h.key;
+		}
+		fin_keys[i] = k;
+	}
+	__syncthreads();
+	for(uint32_t k = 2;k <= np2;k <<= 1){
+		for(uint32_t j = k >> 1;j > 0;j >>= 1){
+			for(uint32_t i = tid;i < np2;i += FINBIG_THREADS){
+				const uint32_t l = i ^ j;
+				if(l > i){
+					const uint64_t a = fin_keys[i], b = fin_keys[l];
+					const bool up = ((i & k) == 0);
+					if((a > b) == up){ fin_keys[i] = b; fin_keys[l] = a; }
+				}
+			}
+			__syncthreads();
+		}
+	}
+	const uint32_t chunk = (np2 + FINBIG_THREADS - 1)/FINBIG_THREADS;
+	const uint32_t lo = min(np2, tid*chunk), hi = min(np2, lo + chunk);
+	uint32_t cnt = 0;
+	for(uint32_t i = lo;i < hi;++i){
+		const uint64_t k = fin_keys[i];
+		if(k != ~0ull && (i == 0 || fin_keys[i - 1] != k)) ++cnt;
+	}
+	part[tid] = cnt;
+	__syncthreads();
+	if(tid == 0){
+		uint32_t run = 0;
+		for(int t = 0;t < FINBIG_THREADS;++t){ const uint32_t c = part[t]; part[t] = run; run += c; }
+		seg_hi[seq] = seq*cap + run;
+	}
+	__syncthreads();
+	uint32_t rank = part[tid];
+	for(uint32_t i = lo;i < hi;++i){
+		const uint64_t k = fin_keys[i];
+		if(k != ~0ull && (i == 0 || fin_keys[i - 1] != k)){
+			DevEntry e;
+			materialise_entry(k, planes, blk_off, irr, irr_off, e);
+			db[(size_t)seq*cap + rank] = e;
+			++rank;
+		}
+	}
+}
+
 // ============================================================================== amplicon screen
 // match_words (optimize.cpp:291-301) of every assay oligo against every DB entry:
 // mask[e][o/32] bit o%32 = entry matches oligo o at or above unsigned(size*thr^2).
@@ -427,24 +506,35 @@ __device__ __forceinline__ bool db_slot(uint32_t g, uint32_t n, uint32_t cap, co
 	return slot < seg_hi[seq];
 }
 
-__global__ void k_match(const DevEntry *__restrict__ db, uint32_t n, uint32_t cap, const uint32_t *__restrict__ touched,
-	const uint32_t *__restrict__ seg_hi, const OligoDev *__restrict__ oligos, uint32_t n_oligo, uint32_t mask_words, uint32_t *__restrict__ mask,
-	uint32_t *__restrict__ status)
+// One wave per touched sequence; a lane = (entry parity, oligo % 32): two DB entries against 32 oligos per
+// step, the 64 compare results leave as one ballot.  (One lane per DB slot walked the oligo list serially:
+// with a handful of filled slots per sequence that was a chain of dependent scalar loads, 20 us at C2.)
+constexpr int MATCH_WAVES = 4;
+__global__ __launch_bounds__(64*MATCH_WAVES) void k_match(const DevEntry *__restrict__ db, uint32_t n_touched, uint32_t cap,
+	const uint32_t *__restrict__ touched, const uint32_t *__restrict__ seg_hi, const OligoDev *__restrict__ oligos, uint32_t n_oligo,
+	uint32_t mask_words, uint32_t *__restrict__ mask, uint32_t *__restrict__ status)
 {
-	const uint32_t t = blockIdx.x*blockDim.x + threadIdx.x;
-	if(t == 0 && status) status[0] = 0;
-	uint32_t i;                                // DB slot; slot i belongs to sequence i/cap, filled range [seq*cap, seg_hi[seq])
-	if(!db_slot(t, n, cap, touched, seg_hi, i)) return;
-	const DevEntry e = db[i];
-	for(uint32_t w = 0;w < mask_words;++w){
-		uint32_t bits = 0;
-		const uint32_t o_end = min(n_oligo, (w + 1)*32);
-		for(uint32_t o = w*32;o < o_end;++o){
-			const Planes m = oligos[o].m;
-			const uint32_t cnt = __popc((e.w.a & m.a) | (e.w.c & m.c) | (e.w.g & m.g) | (e.w.t & m.t));
-			bits |= (uint32_t)(cnt >= oligos[o].floor2) << (o & 31);
+	if(blockIdx.x == 0 && threadIdx.x == 0 && status) status[0] = 0;
+	const uint32_t t_idx = blockIdx.x*MATCH_WAVES + (threadIdx.x >> 6);
+	if(t_idx >= n_touched) return;
+	const uint32_t lane = threadIdx.x & 63u, sub = lane >> 5, ol = lane & 31u;
+	const uint32_t seq = touched[t_idx];
+	const uint32_t lo = seq*cap, n_e = seg_hi[seq] - lo;         // filled slots [lo, seg_hi[seq])
+	for(uint32_t e0 = 0;e0 < n_e;e0 += 2){
+		const bool have = e0 + sub < n_e;
+		const uint32_t i = lo + e0 + sub;
+		Planes w; w.a = w.c = w.g = w.t = 0;
+		if(have) w = db[i].w;
+		for(uint32_t mw = 0;mw < mask_words;++mw){
+			const uint32_t o = mw*32 + ol;
+			bool ok = false;
+			if(have && o < n_oligo){
+				const Planes m = oligos[o].m;
+				ok = (uint32_t)__popc((w.a & m.a) | (w.c & m.c) | (w.g & m.g) | (w.t & m.t)) >= oligos[o].floor2;
+			}
+			const uint64_t bal = __ballot(ok);
+			if(have && ol == 0) mask[(size_t)i*mask_words + mw] = sub ? (uint32_t)(bal >> 32) : (uint32_t)bal;
 		}
-		mask[(size_t)i*mask_words + w] = bits;
 	}
 }
 
@@ -578,6 +668,7 @@ struct SeqSet {
 	std::vector<std::vector<pcrhost::IrrEntry> > irr_host;
 	uint64_t total_blocks = 0;
 	uint32_t n_tiles = 0, n_irr = 0;
+	DevBuf<uint32_t> irr_perm; uint32_t irr_size_count[256];   // irregular words by size counter, largest first
 	DevBuf<uint4> planes;
 	DevBuf<uint32_t> valid, nib, tb, blk_seq, tile_seq, tile_pos0, irr_off, seg_lo, seg_hi, degen_tiles;
 	DevBuf<uint8_t> tile_degen; uint32_t n_degen_tiles = 0;
@@ -597,7 +688,7 @@ struct SeqSet {
 	uint32_t *d_seg_hi = nullptr;
 	void release()
 	{
-		planes.release(); valid.release(); nib.release(); tb.release(); degen_tiles.release(); tile_degen.release(); blk_seq.release(); tile_seq.release(); tile_pos0.release();
+		irr_perm.release(); planes.release(); valid.release(); nib.release(); tb.release(); degen_tiles.release(); tile_degen.release(); blk_seq.release(); tile_seq.release(); tile_pos0.release();
 		irr_off.release(); seg_lo.release(); seg_hi.release(); d_len.release(); d_blk_off.release();
 		d_nblk_real.release(); d_active.release(); irr.release(); db.release(); touched.release(); ctrl.release(); codes.release(); d_code_off.release();
 	}
@@ -624,10 +715,14 @@ struct pcr_ctx {
 	DevBuf<thermo::Job> th_jobs; DevBuf<thermo::JobOut> th_out; DevBuf<int> th_dg, th_scratch_i; DevBuf<unsigned short> th_scratch_s;
 	size_t amp_cap = size_t(1) << 20;
 	uint32_t bucket_cap = 64;   // hit slots per sequence (grows on overflow)
+	DevBuf<uint64_t> fin_scratch;   // k_finalize_big's keys
 	uint32_t epoch = 0;         // pass counter tagging best[] (see HitSink)
 	uint32_t *best_seen = nullptr;
 	// pinned staging for the small per-call host->device payload (candidates, tables, oligos): one async copy
-	uint8_t *stage = nullptr; size_t stage_cap = 0; hipEvent_t stage_done = nullptr; bool stage_busy = false;
+	uint8_t *stage = nullptr, *stage_dev = nullptr; size_t stage_cap = 0; hipEvent_t stage_done = nullptr; bool stage_busy = false;
+	struct Mail { volatile uint32_t counters[4]; volatile uint32_t seq; uint32_t pad[11]; };
+	Mail *mail = nullptr, *mail_dev = nullptr;   // host-mapped: k_publish writes it, the host spins on seq
+	uint32_t mail_seq = 0;
 	DevBuf<uint8_t> arena;
 	const uint4 *d_cand_fwd = nullptr, *d_cand_rc = nullptr; const uint32_t *d_cand_floor = nullptr, *d_tab = nullptr, *d_bias = nullptr;
 	const OligoDev *d_oligos = nullptr;
@@ -656,7 +751,16 @@ int upload_irregular(pcr_ctx *ctx, SeqSet &S)
 	}
 	off[S.n] = (uint32_t)flat.size();
 	S.n_irr = (uint32_t)flat.size();
+	// scan order: by size counter, largest first, so that a pass with min_oligo_length m walks a prefix
+	// (sequence.cpp:157,239 drop the words whose counter is below m)
+	std::vector<uint32_t> perm(flat.size());
+	for(size_t i = 0;i < perm.size();++i) perm[i] = (uint32_t)i;
+	std::stable_sort(perm.begin(), perm.end(), [&flat](uint32_t a, uint32_t b){ return ((flat[a].meta >> 8) & 0xFF) > ((flat[b].meta >> 8) & 0xFF); });
+	for(int k = 0;k < 256;++k) S.irr_size_count[k] = 0;
+	for(const IrrDev &d : flat) ++S.irr_size_count[(d.meta >> 8) & 0xFF];
 	int rc;
+	if((rc = S.irr_perm.ensure(perm.size() + 1)) != PCR_OK) return rc;
+	if(!perm.empty()) HIP_TRY(hipMemcpyAsync(S.irr_perm.p, perm.data(), perm.size()*sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
 	if((rc = S.irr.ensure(flat.size())) != PCR_OK) return rc;
 	if((rc = S.irr_off.ensure(off.size())) != PCR_OK) return rc;
 	if(!flat.empty()) HIP_TRY(hipMemcpyAsync(S.irr.p, flat.data(), flat.size()*sizeof(IrrDev), hipMemcpyHostToDevice, ctx->stream));
@@ -688,7 +792,19 @@ void fill_oligo(OligoDev &o, const uint64_t w[2], float thr2)
 	o.p2 = (o.stop >= 0) ? pcrhost::planes_nibble(o.m, o.stop) : 0;
 }
 
-// Packs small host arrays into the pinned staging buffer and ships them with ONE async copy.
+// Packs small host arrays into a host-mapped pinned buffer; ONE kernel (k_stage) pulls them into the
+// device arena and clears up to two device regions in the same launch -- a copy-engine transfer and a
+// fill each cost ~4 us plus a ~6 us queue bubble on either side, a kernel runs back to back with the next.
+__global__ void k_stage(const uint4 *__restrict__ src, uint4 *__restrict__ dst, uint32_t n16,
+	uint4 *__restrict__ z0, uint32_t n0, uint4 *__restrict__ z1, uint32_t n1)
+{
+	const uint32_t i = blockIdx.x*blockDim.x + threadIdx.x, stride = gridDim.x*blockDim.x;
+	for(uint32_t k = i;k < n16;k += stride) dst[k] = src[k];
+	const uint4 zero = make_uint4(0, 0, 0, 0);
+	for(uint32_t k = i;k < n0;k += stride) z0[k] = zero;
+	for(uint32_t k = i;k < n1;k += stride) z1[k] = zero;
+}
+
 struct Stager {
 	pcr_ctx *ctx; size_t used = 0;
 	explicit Stager(pcr_ctx *c) : ctx(c) {}
@@ -698,7 +814,8 @@ struct Stager {
 		if(bytes > ctx->stage_cap){
 			if(ctx->stage){ (void)hipHostFree(ctx->stage); ctx->stage = nullptr; ctx->stage_cap = 0; }
 			const size_t want = std::max<size_t>(bytes*2, 1 << 16);
-			HIP_TRY(hipHostMalloc((void **)&ctx->stage, want, hipHostMallocDefault));
+			HIP_TRY(hipHostMalloc((void **)&ctx->stage, want, hipHostMallocMapped | hipHostMallocCoherent));
+			HIP_TRY(hipHostGetDevicePointer((void **)&ctx->stage_dev, ctx->stage, 0));
 			ctx->stage_cap = want;
 		}
 		if(!ctx->stage_done) HIP_TRY(hipEventCreateWithFlags(&ctx->stage_done, hipEventDisableTiming));
@@ -715,28 +832,64 @@ struct Stager {
 		used += n*sizeof(T);
 		return dev;
 	}
-	int ship()
+	// z0/z1: device regions to clear in the same launch (16-byte aligned, sizes rounded UP to 16 bytes: the
+	// caller's buffers must be allocated with that slack)
+	int ship(void *z0 = nullptr, size_t bytes0 = 0, void *z1 = nullptr, size_t bytes1 = 0)
 	{
-		if(used) HIP_TRY(hipMemcpyAsync(ctx->arena.p, ctx->stage, used, hipMemcpyHostToDevice, ctx->stream));
+		const uint32_t n16 = (uint32_t)((used + 15)/16), n0 = (uint32_t)((bytes0 + 15)/16), n1 = (uint32_t)((bytes1 + 15)/16);
+		const uint32_t most = std::max(n16, std::max(n0, n1));
+		if(most){
+			const unsigned grid = std::min<unsigned>((most + 255)/256, 512u);
+			hipLaunchKernelGGL(k_stage, dim3(grid), dim3(256), 0, ctx->stream, (const uint4 *)ctx->stage_dev, (uint4 *)ctx->arena.p, n16,
+				(uint4 *)z0, n0, (uint4 *)z1, n1);
+			HIP_TRY(hipGetLastError());
+		}
 		HIP_TRY(hipEventRecord(ctx->stage_done, ctx->stream));
 		ctx->stage_busy = true;
 		return PCR_OK;
 	}
 };
 
+// The pass's counters go to the host through mapped memory: no copy-engine packet, no interrupt wake-up.
+__global__ void k_publish(const uint32_t *__restrict__ counters, pcr_ctx::Mail *mail, uint32_t seq)
+{
+	if(threadIdx.x < 4) mail->counters[threadIdx.x] = counters[threadIdx.x];
+	__threadfence_system();
+	__syncthreads();
+	if(threadIdx.x == 0) __hip_atomic_store((uint32_t *)&mail->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+int mail_wait(pcr_ctx *ctx, uint32_t seq, uint32_t out[4])
+{
+	uint64_t spins = 0;
+	while(__atomic_load_n((const uint32_t *)&ctx->mail->seq, __ATOMIC_ACQUIRE) != seq){
+		__builtin_ia32_pause();
+		if((++spins & 0x3FFF) == 0){
+			const hipError_t e = hipStreamQuery(ctx->stream);
+			if(e == hipSuccess){                          // everything drained: the flag must be there now
+				if(__atomic_load_n((const uint32_t *)&ctx->mail->seq, __ATOMIC_ACQUIRE) == seq) break;
+				g_err = "device pass finished without publishing its counters"; return PCR_ERR_DEVICE;
+			}
+			if(e != hipErrorNotReady){ g_err = std::string("device pass failed: ") + hipGetErrorString(e); return PCR_ERR_DEVICE; }
+		}
+	}
+	for(int i = 0;i < 4;++i) out[i] = ctx->mail->counters[i];
+	return PCR_OK;
+}
+
 int amplify_launch(pcr_ctx *ctx, SeqSet &S, const pcr_pair *pairs, uint32_t n_pairs, const pcr_amplify_args *a,
 	uint64_t *d_fr, uint64_t *d_rf)
 {
 	if(!S.have_db){ g_err = "pcr_amplify: no word DB (call pcr_select_words first)"; return PCR_ERR_STATE; }
 	const uint64_t words = (S.n + 63)/64;
-	if(d_rf == d_fr + (size_t)n_pairs*words){
-		HIP_TRY(hipMemsetAsync(d_fr, 0, 2*(size_t)n_pairs*words*sizeof(uint64_t), ctx->stream));
+	const size_t bits_bytes = (size_t)n_pairs*words*sizeof(uint64_t);
+	if(S.n_entries == 0 || n_pairs == 0){
+		if(bits_bytes){
+			HIP_TRY(hipMemsetAsync(d_fr, 0, bits_bytes, ctx->stream));
+			HIP_TRY(hipMemsetAsync(d_rf, 0, bits_bytes, ctx->stream));
+		}
+		return PCR_OK;
 	}
-	else{
-		HIP_TRY(hipMemsetAsync(d_fr, 0, (size_t)n_pairs*words*sizeof(uint64_t), ctx->stream));
-		HIP_TRY(hipMemsetAsync(d_rf, 0, (size_t)n_pairs*words*sizeof(uint64_t), ctx->stream));
-	}
-	if(S.n_entries == 0 || n_pairs == 0) return PCR_OK;
 	const float thr2 = a->collect_threshold*a->collect_threshold;                // pcr_assay.cpp:31-32
 	std::vector<OligoDev> ol(2*(size_t)n_pairs);
 	for(uint32_t i = 0;i < n_pairs;++i){
@@ -747,7 +900,13 @@ int amplify_launch(pcr_ctx *ctx, SeqSet &S, const pcr_pair *pairs, uint32_t n_pa
 	Stager st(ctx);
 	if((rc = st.begin(ol.size()*sizeof(OligoDev) + 64)) != PCR_OK) return rc;
 	ctx->d_oligos = st.put(ol.data(), ol.size());
-	if((rc = st.ship()) != PCR_OK) return rc;
+	// the result bitsets are cleared by the staging kernel when they allow 16-byte stores
+	const bool vec_ok = ((uintptr_t)d_fr % 16 == 0) && ((uintptr_t)d_rf % 16 == 0) && (bits_bytes % 16 == 0);
+	if(!vec_ok){
+		HIP_TRY(hipMemsetAsync(d_fr, 0, bits_bytes, ctx->stream));
+		HIP_TRY(hipMemsetAsync(d_rf, 0, bits_bytes, ctx->stream));
+	}
+	if((rc = vec_ok ? st.ship(d_fr, bits_bytes, d_rf, bits_bytes) : st.ship()) != PCR_OK) return rc;
 	const uint32_t mask_words = (2*n_pairs + 31)/32;
 	if((rc = ctx->mask.ensure((size_t)S.n_slots*mask_words)) != PCR_OK) return rc;
 	if((rc = ctx->status.ensure(1)) != PCR_OK) return rc;
@@ -755,8 +914,8 @@ int amplify_launch(pcr_ctx *ctx, SeqSet &S, const pcr_pair *pairs, uint32_t n_pa
 	const uint32_t n_db = S.n_touched*S.db_cap;
 	const unsigned grid = (n_db + threads - 1)/threads;
 	// k_match also clears the status word (it runs before k_pair in stream order)
-	hipLaunchKernelGGL(k_match, dim3(grid), dim3(threads), 0, ctx->stream, S.db.p, n_db, S.db_cap, S.touched.p, S.d_seg_hi, ctx->d_oligos,
-		2*n_pairs, mask_words, ctx->mask.p, ctx->status.p);
+	hipLaunchKernelGGL(k_match, dim3((S.n_touched + MATCH_WAVES - 1)/MATCH_WAVES), dim3(64*MATCH_WAVES), 0, ctx->stream, S.db.p, S.n_touched, S.db_cap,
+		S.touched.p, S.d_seg_hi, ctx->d_oligos, 2*n_pairs, mask_words, ctx->mask.p, ctx->status.p);
 	HIP_TRY(hipGetLastError());
 	hipLaunchKernelGGL(k_pair, dim3(grid), dim3(threads), 0, ctx->stream, S.db.p, n_db, S.db_cap, S.touched.p, S.d_seg_hi, ctx->mask.p,
 		mask_words, ctx->d_oligos, n_pairs, S.planes.p, S.d_blk_off.p, S.d_len.p, S.d_active.p, a->amp_min, a->amp_max,
@@ -868,6 +1027,11 @@ pcr_ctx *pcr_create(int device, void *hip_stream, const pcr_params *params)
 	   hipMemcpyToSymbol(HIP_SYMBOL(thermo::c_wc), PCR_WC, sizeof(PCR_WC)) != hipSuccess){
 		g_err = "pcr_create: hipMemcpyToSymbol failed"; delete ctx; return nullptr;
 	}
+	if(hipHostMalloc((void **)&ctx->mail, sizeof(pcr_ctx::Mail), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+	   hipHostGetDevicePointer((void **)&ctx->mail_dev, ctx->mail, 0) != hipSuccess){
+		g_err = "pcr_create: mapped host allocation failed"; if(ctx->mail) (void)hipHostFree(ctx->mail); delete ctx; return nullptr;
+	}
+	memset((void *)ctx->mail, 0, sizeof(pcr_ctx::Mail));
 	return ctx;
 }
 
@@ -880,8 +1044,9 @@ void pcr_destroy(pcr_ctx *ctx)
 	for(int s = 0;s < 2;++s) ctx->sets[s].release();
 	ctx->cand_fwd.release(); ctx->cand_rc.release(); ctx->cand_floor.release(); ctx->best.release();
 	ctx->counters.release(); ctx->mask.release(); ctx->status.release(); ctx->hits.release();
-	ctx->bits_fr.release(); ctx->bits_rf.release(); ctx->arena.release();
+	ctx->bits_fr.release(); ctx->bits_rf.release(); ctx->arena.release(); ctx->fin_scratch.release();
 	if(ctx->stage) (void)hipHostFree(ctx->stage);
+	if(ctx->mail) (void)hipHostFree(ctx->mail);
 	if(ctx->stage_done) (void)hipEventDestroy(ctx->stage_done);
 	ctx->oligos.release(); ctx->tab.release(); ctx->bias.release(); ctx->sw_jobs.release(); ctx->sw_out.release(); ctx->sw_q.release(); ctx->sw_qlen.release(); ctx->sw_t.release(); ctx->entry_codes.release(); ctx->entry_lens.release(); ctx->amp_recs.release(); ctx->bg_pairs.release(); ctx->th_jobs.release(); ctx->th_out.release(); ctx->th_dg.release(); ctx->th_scratch_i.release(); ctx->th_scratch_s.release();
 	if(ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
@@ -991,6 +1156,7 @@ int pcr_load_sequences(pcr_ctx *ctx, pcr_set which, const uint8_t *packed4, cons
 		if(hipGetLastError() != hipSuccess){ g_err = "k_transpose launch failed"; return fail(PCR_ERR_DEVICE); }
 		if((rc = run_valid(ctx, S, 0, total_blocks)) != PCR_OK) return fail(rc);
 	}
+	ctx->bucket_cap = 64;            // grown by earlier passes over other data: start small again
 	S.n_degen_tiles = 0;
 	if(n_tiles){
 		hipLaunchKernelGGL(k_tile_degen, dim3((unsigned)((n_tiles + 255)/256)), dim3(256), 0, ctx->stream, S.planes.p, S.d_blk_off.p,
@@ -1183,11 +1349,12 @@ int pcr_select_words(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_
 			d_map_seedset = st.put(m.data(), m.size());
 		}
 		if(!image.empty()) ST.image = st.put(image.data(), image.size());
-		if((rc = st.ship()) != PCR_OK) return rc;
+		// the same launch clears the pass's control block (counters | per-sequence fills | segment ends)
+		if((rc = S.ctrl.ensure(8 + 2*(size_t)S.n + 4)) != PCR_OK) return rc;
+		if((rc = st.ship(S.ctrl.p, (8 + 2*(size_t)S.n)*sizeof(uint32_t))) != PCR_OK) return rc;
 	}
 
 	uint32_t h_counters[4];
-	if((rc = S.ctrl.ensure(8 + 2*(size_t)S.n)) != PCR_OK) return rc;
 	if((rc = S.touched.ensure(S.n)) != PCR_OK) return rc;
 	uint32_t *const d_counters = S.ctrl.p, *const d_seq_count = S.ctrl.p + 8;
 	S.d_seg_hi = S.ctrl.p + 8 + S.n;
@@ -1199,7 +1366,7 @@ int pcr_select_words(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_
 		}
 		if((rc = ctx->hits.ensure(n_slots)) != PCR_OK) return rc;
 		if((rc = S.db.ensure(n_slots)) != PCR_OK) return rc;
-		HIP_TRY(hipMemsetAsync(S.ctrl.p, 0, (8 + 2*(size_t)S.n)*sizeof(uint32_t), ctx->stream));
+		if(attempt > 0) HIP_TRY(hipMemsetAsync(S.ctrl.p, 0, (8 + 2*(size_t)S.n)*sizeof(uint32_t), ctx->stream));
 		++ctx->epoch;
 		HitSink sink; sink.best = ctx->best.p; sink.hits = ctx->hits.p; sink.seq_count = d_seq_count;
 		sink.counters = d_counters; sink.cap = cap; sink.ncand = ncand; sink.epoch = ctx->epoch;
@@ -1236,28 +1403,37 @@ int pcr_select_words(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_
 				ctx->prof_events.push_back(std::make_pair(e0, e1));
 			}
 		}
-		if(S.n_irr){
-			const unsigned irr_grid = std::min<unsigned>((S.n_irr + IRR_THREADS - 1)/IRR_THREADS, 1024u);
-			hipLaunchKernelGGL(k_scan_irr, dim3(irr_grid), dim3(IRR_THREADS), 0, ctx->stream, S.irr.p,
-				S.n_irr, S.d_active.p, min_oligo_length, ctx->d_cand_fwd, ctx->d_cand_floor, ncand, sink);
+		uint32_t n_live = 0;
+		for(uint32_t k = std::min<uint32_t>(min_oligo_length, 256);k < 256;++k) n_live += S.irr_size_count[k];
+		if(n_live){
+			const unsigned irr_grid = (n_live + IRR_THREADS*IRR_PER_LANE - 1)/(IRR_THREADS*IRR_PER_LANE);
+			hipLaunchKernelGGL(k_scan_irr, dim3(irr_grid), dim3(IRR_THREADS), 0, ctx->stream, S.irr.p, S.irr_perm.p, n_live,
+				S.d_active.p, ctx->d_cand_fwd, ctx->d_cand_floor, ncand, sink);
 			HIP_TRY(hipGetLastError());
 		}
 		hipLaunchKernelGGL(k_touched, dim3((S.n + 255)/256), dim3(256), 0, ctx->stream, d_seq_count, S.n, d_counters, S.touched.p);
 		HIP_TRY(hipGetLastError());
 		uint32_t np2 = 1; while(np2 < cap) np2 <<= 1;
-		hipLaunchKernelGGL(k_finalize, dim3((S.n + FIN_WAVES - 1)/FIN_WAVES), dim3(FIN_THREADS), (size_t)FIN_WAVES*np2*sizeof(uint64_t), ctx->stream,
-			ctx->hits.p, d_seq_count, cap, ctx->best.p, ncand, S.planes.p, S.d_blk_off.p, S.irr.p, S.irr_off.p, S.db.p, S.d_seg_hi,
-			d_counters, ctx->epoch, S.touched.p);
+#define FIN_ARGS ctx->hits.p, d_seq_count, cap, ctx->best.p, ncand, S.planes.p, S.d_blk_off.p, S.irr.p, S.irr_off.p, S.db.p, S.d_seg_hi, \
+	d_counters, ctx->epoch, S.touched.p
+		if(np2 <= 1024) hipLaunchKernelGGL(k_finalize<FIN_WAVES>, dim3((S.n + FIN_WAVES - 1)/FIN_WAVES), dim3(64*FIN_WAVES), (size_t)FIN_WAVES*np2*sizeof(uint64_t), ctx->stream, FIN_ARGS);
+		else if(np2 <= MAX_BUCKET_CAP) hipLaunchKernelGGL(k_finalize<1>, dim3(S.n), dim3(64), (size_t)np2*sizeof(uint64_t), ctx->stream, FIN_ARGS);
+		else{
+			if((rc = ctx->fin_scratch.ensure((size_t)S.n*np2)) != PCR_OK) return rc;
+			hipLaunchKernelGGL(k_finalize_big, dim3(S.n), dim3(FINBIG_THREADS), 0, ctx->stream, FIN_ARGS, ctx->fin_scratch.p);
+		}
+#undef FIN_ARGS
 		HIP_TRY(hipGetLastError());
-		// the only host synchronisation of the pass: overflow flag + DB size
-		HIP_TRY(hipMemcpyAsync(h_counters, d_counters, sizeof(h_counters), hipMemcpyDeviceToHost, ctx->stream));
-		HIP_TRY(hipStreamSynchronize(ctx->stream));
+		// the only host synchronisation of the pass: overflow flag + DB size, through the mapped mailbox
+		hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, ctx->stream, d_counters, ctx->mail_dev, ++ctx->mail_seq);
+		HIP_TRY(hipGetLastError());
+		if((rc = mail_wait(ctx, ctx->mail_seq, h_counters)) != PCR_OK) return rc;
 		S.db_cap = cap; S.n_slots = n_slots;
 		if(!(h_counters[0] & 1u)) break;
 		// some sequence collected more hits than its bucket holds: grow the buckets and redo the pass
-		if(attempt >= 8 || cap >= 1024){ g_err = "pcr_select_words: more than 1024 tied candidate sites in one sequence (per-sequence bucket limit)"; return PCR_ERR_CAPACITY; }
+		if(attempt >= 12 || cap >= MAX_BUCKET_CAP_GLOBAL){ g_err = "pcr_select_words: more than 65536 candidate sites in one sequence (per-sequence bucket limit)"; return PCR_ERR_CAPACITY; }
 		uint32_t want = cap*2;
-		while(want < h_counters[2] && want < 1024) want *= 2;
+		while(want < h_counters[2] && want < MAX_BUCKET_CAP_GLOBAL) want *= 2;
 		ctx->bucket_cap = want;
 	}
 	S.n_touched = h_counters[3];
@@ -1440,6 +1616,19 @@ int64_t pcr_host_candidates(const pcr_pair *pairs, uint32_t n_pairs, int optimiz
 	return (int64_t)cand.size();
 }
 
+int64_t pcr_host_orientation_seeds(const pcr_word128 *oligo, uint32_t floor, uint32_t *codes, uint8_t *q, uint8_t *off, uint64_t cap)
+{
+	if(!oligo){ g_err = "null oligo"; return PCR_ERR_ARG; }
+	std::vector<pcrhost::Seed> seeds;
+	if(!pcrhost::orientation_seeds(pcrhost::planes_of_word(oligo->w), floor, 0, seeds)) return -1;
+	for(size_t i = 0;i < seeds.size() && i < cap;++i){
+		if(codes) codes[i] = seeds[i].code;
+		if(q) q[i] = seeds[i].q;
+		if(off) off[i] = seeds[i].off;
+	}
+	return (int64_t)seeds.size();
+}
+
 } // extern "C"
 
 // ------------------------------------------------------------------ Smith-Waterman entry points
@@ -1561,7 +1750,8 @@ int pcr_background_match(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uin
 	const unsigned threads = 128;
 	const uint32_t n_db = S.n_touched*S.db_cap;
 	const unsigned grid = (n_db + threads - 1)/threads;
-	hipLaunchKernelGGL(k_match, dim3(grid), dim3(threads), 0, ctx->stream, S.db.p, n_db, S.db_cap, S.touched.p, S.d_seg_hi, ctx->oligos.p, 2*n_pairs, mask_words, ctx->mask.p, (uint32_t *)nullptr);
+	hipLaunchKernelGGL(k_match, dim3((S.n_touched + MATCH_WAVES - 1)/MATCH_WAVES), dim3(64*MATCH_WAVES), 0, ctx->stream, S.db.p, S.n_touched, S.db_cap,
+		S.touched.p, S.d_seg_hi, ctx->oligos.p, 2*n_pairs, mask_words, ctx->mask.p, (uint32_t *)nullptr);
 	HIP_TRY(hipGetLastError());
 	uint32_t n_amp = 0, status = 0;
 	for(int attempt = 0;;++attempt){

@@ -1,0 +1,163 @@
+"""The seed scan (default match scan of pcr_select_words) against the bit-sliced scan and the
+oracle: tile borders, many candidates, duplicated primers, IUPAC on either side, dense hits.
+The word DB must be identical entry for entry.  Run on the GPU box with `-m gpu`."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+from pcramp_amd import api
+from testdata import rand_seq, revcomp, mutate
+
+pytestmark = pytest.mark.gpu
+
+
+def _screener(scan):
+    old = os.environ.get("PCRAMP_SCAN")
+    if scan is None:
+        os.environ.pop("PCRAMP_SCAN", None)
+    else:
+        os.environ["PCRAMP_SCAN"] = str(scan)
+    try:
+        return api.Screener(0)
+    finally:
+        if old is None:
+            os.environ.pop("PCRAMP_SCAN", None)
+        else:
+            os.environ["PCRAMP_SCAN"] = old
+
+
+@pytest.fixture(scope="module")
+def both():
+    a, b = _screener(None), _screener(2)
+    yield a, b
+    a.close()
+    b.close()
+
+
+def _entries(dev, seqs, pairs, thr, opt5=0, opt3=0, min_len=18):
+    dev.load_texts(seqs, [1.0] * len(seqs))
+    n = dev.select_words(pairs, thr, min_len, opt5, opt3)
+    e = dev.entries()
+    assert len(e) == n
+    return e
+
+
+def _oracle_entries(oracle, seqs, pairs, thr_t, mult, opt5=0, opt3=0):
+    so = oracle.session(target_threshold=thr_t, search_multiplier=mult, amp_min=80, amp_max=200, use_taq_mama=0,
+                        pack_max_degen=256, pack_min_gc=0.0, pack_max_gc=1.0, min_primer=18, optimize_5=opt5, optimize_3=opt3)
+    for s in seqs:
+        so.add_target(s, 1.0)
+    so.select(pairs)
+    return so.db_entries()
+
+
+def _border_case(rng, oracle):
+    """Primer sites planted so that windows start just before / on / after every kind of tile border."""
+    seqs, pairs = [], []
+    for L in (1023, 1024, 1025, 1055, 1056, 1057, 2047, 2048, 2080, 3100, 5000):
+        s = list(rand_seq(rng, L))
+        seqs.append("".join(s))
+    base = seqs[-1]
+    for start in (0, 1, 990, 1000, 1003, 1010, 1020, 1023, 1024, 1025, 1040, 2030, 2047, 2048, 2050, 4960, 4975):
+        ln = rng.randint(18, 25)
+        if start + ln + 150 > len(base):
+            f = base[start - 150:start - 150 + 20]
+            r = revcomp(base[start:start + ln])
+        else:
+            f = base[start:start + ln]
+            r = revcomp(base[start + 100:start + 100 + rng.randint(18, 25)])
+        pairs.append((oracle.centered_word(f), oracle.centered_word(r)))
+    # near-copies of the long sequence: sites with 1-3 substitutions
+    for _ in range(4):
+        seqs.append(mutate(rng, base, 0.03))
+    return seqs, pairs
+
+
+@pytest.mark.parametrize("thr_t,mult", [(1.0, 0.9), (0.95, 0.9), (1.0, 0.95), (0.9, 0.9)])
+def test_tile_borders(both, oracle, thr_t, mult):
+    rng = random.Random(991)
+    seqs, pairs = _border_case(rng, oracle)
+    thr = float(np.float32(thr_t) * np.float32(mult))
+    e3 = _entries(both[0], seqs, pairs, thr)
+    e2 = _entries(both[1], seqs, pairs, thr)
+    assert e3 == e2
+    assert e3 == _oracle_entries(oracle, seqs, pairs, thr_t, mult)
+    assert len(e3) > 0
+
+
+def test_many_candidates_and_duplicates(both, oracle):
+    """5'/3' shift candidates (> 256 candidates: planes read from global memory instead of LDS) and the same
+    primer listed several times (several seeds per q-gram code)."""
+    rng = random.Random(77)
+    root = rand_seq(rng, 2600)
+    seqs = [root] + [mutate(rng, root, 0.03) for _ in range(9)] + [rand_seq(rng, 1500) for _ in range(3)]
+    pairs = []
+    for i in range(24):
+        a = rng.randrange(0, 2300)
+        f = root[a:a + rng.randint(18, 25)]
+        r = revcomp(root[a + 120:a + 120 + rng.randint(18, 25)])
+        pairs.append((oracle.centered_word(f), oracle.centered_word(r)))
+    pairs = pairs + pairs[:6] + pairs[:3]
+    thr = float(np.float32(1.0) * np.float32(0.9))
+    n_cand = len(api.host_candidates(pairs, True, True, thr)[1])
+    assert n_cand > 256
+    e3 = _entries(both[0], seqs, pairs, thr, 1, 1)
+    e2 = _entries(both[1], seqs, pairs, thr, 1, 1)
+    assert e3 == e2
+    assert e3 == _oracle_entries(oracle, seqs, pairs, 1.0, 0.9, 1, 1)
+
+
+def test_iupac_both_sides(both, oracle):
+    rng = random.Random(5)
+    root = rand_seq(rng, 3000)
+    seqs = [root]
+    for i in range(6):
+        s = list(mutate(rng, root, 0.02))
+        for _ in range(i * 3):                                   # tiles with and without IUPAC target codes
+            s[rng.randrange(len(s))] = rng.choice("RYKMSWN")
+        seqs.append("".join(s))
+    pairs = []
+    for i in range(16):
+        a = rng.randrange(0, 2700)
+        f, r = list(root[a:a + rng.randint(18, 25)]), list(revcomp(root[a + 110:a + 110 + rng.randint(18, 25)]))
+        for o in (f, r):
+            for _ in range(rng.choice([0, 1, 2, 4])):
+                o[rng.randrange(len(o))] = rng.choice("RYKMSWBDHVN")
+        pairs.append((oracle.centered_word("".join(f)), oracle.centered_word("".join(r))))
+    for thr_t in (1.0, 0.95):
+        thr = float(np.float32(thr_t) * np.float32(0.9))
+        e3 = _entries(both[0], seqs, pairs, thr)
+        e2 = _entries(both[1], seqs, pairs, thr)
+        assert e3 == e2
+        assert e3 == _oracle_entries(oracle, seqs, pairs, thr_t, 0.9)
+
+
+def test_dense_hits_low_complexity(both, oracle):
+    """Low-complexity targets: almost every position is a seed hit and very many windows tie at the maximum
+    (bucket growth, multi-seed codes, verification in every lane)."""
+    rng = random.Random(12)
+    seqs = ["A" * 700 + rand_seq(rng, 300) + "AC" * 300, "ACGT" * 400, "A" * 40 + "C" + "A" * 500, rand_seq(rng, 1200)]
+    txt = [("A" * 20, "T" * 20), ("AC" * 10, "GT" * 10), ("ACGT" * 5, "ACGT" * 5), ("A" * 19 + "C", "T" * 18)]
+    pairs = [(oracle.centered_word(f), oracle.centered_word(r)) for f, r in txt]
+    thr = float(np.float32(1.0) * np.float32(0.9))
+    e3 = _entries(both[0], seqs, pairs, thr)
+    e2 = _entries(both[1], seqs, pairs, thr)
+    assert e3 == e2
+    assert e3 == _oracle_entries(oracle, seqs, pairs, 1.0, 0.9)
+    assert len(e3) > 1000
+
+
+def test_bench_shape_sample(both):
+    """A slice of the bench workload (families of 50 at 3 %): seed scan == bit-sliced scan at full length."""
+    from pcramp_amd import synth
+    wl = synth.workload("C2", 0, 0.03)
+    thr = float(np.float32(1.0) * np.float32(0.9))
+    out = []
+    for d in both:
+        d.load_sequences(wl["packed"], wl["byte_offsets"], wl["lengths"], np.ones(wl["T"], np.float32))
+        n = d.select_words(wl["pairs"], thr, 18)
+        out.append((n, d.entries()))
+    assert out[0] == out[1]
+    assert out[0][0] > 0

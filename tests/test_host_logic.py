@@ -133,3 +133,58 @@ def test_no_gpu_fails_loudly():
         pytest.skip("GPU present")
     with pytest.raises(api.PcrError):
         api.Screener(0)
+
+
+# ---------------------------------------------------------------------------- seed scan filter
+def _match_count(slots_oligo, window_codes):
+    """Word::operator& (word.h): slots whose base sets intersect."""
+    return sum(1 for k in range(32) if slots_oligo[k] & window_codes[k])
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_seed_filter_is_a_necessary_condition(seed):
+    """Every 32-base ACGT window that reaches the floor must contain one of the orientation's
+    seeds at its offset (the pigeonhole argument the seed scan relies on); random windows planted
+    with up to k mismatches, plus the exact site, are all caught."""
+    rng = random.Random(4200 + seed)
+    two_bit = {1: 0, 2: 1, 4: 2, 8: 3}
+    n_seedable = 0
+    for _ in range(60):
+        size = rng.randint(18, 32)
+        codes = [rng.choice([1, 2, 4, 8]) for _ in range(size)]
+        for _ in range(rng.choice([0, 0, 1, 2, 3])):           # IUPAC positions in the oligo
+            codes[rng.randrange(size)] = rng.choice([3, 5, 6, 9, 10, 12, 7, 11, 13, 14, 15])
+        word = W.centered_word(np.array(codes, dtype=np.uint8))
+        slots = [int(v) for v in W.slots_from_word(word)]
+        thr = rng.choice([0.95, 0.9, 0.9, 0.85, 0.8, 0.7])
+        floor = int(np.float32(size) * np.float32(thr))
+        seeds = api.host_orientation_seeds(word, floor)
+        if seeds is None:
+            continue
+        n_seedable += 1
+        occ = [k for k in range(32) if slots[k]]
+        k_max = size - floor
+        for trial in range(40):
+            win = [rng.choice([1, 2, 4, 8]) for _ in range(32)]
+            for k in occ:                                       # plant a site ...
+                win[k] = rng.choice([b for b in (1, 2, 4, 8) if slots[k] & b])
+            for k in rng.sample(occ, rng.randint(0, k_max)):    # ... with at most k mismatching slots
+                bad = [b for b in (1, 2, 4, 8) if not (slots[k] & b)]
+                if bad:
+                    win[k] = rng.choice(bad)
+            assert _match_count(slots, win) >= floor
+            hit = False
+            for code, q, off in seeds:
+                if all(two_bit[win[off + j]] == ((code >> (2 * j)) & 3) for j in range(q)):
+                    hit = True
+                    break
+            assert hit, (size, floor, seeds, win)
+    assert n_seedable > 10
+
+
+def test_seed_filter_declines_low_thresholds():
+    word = W.centered_word(W.codes_from_text("ACGTACGTACGTACGTACGT"))
+    assert api.host_orientation_seeds(word, 10) is None        # 11 blocks of <2 bases: not seedable
+    assert api.host_orientation_seeds(word, 0) is None         # floor 0: every window matches
+    s = api.host_orientation_seeds(word, 18)                   # k = 2 -> 3 blocks
+    assert s is not None and len(s) == 3 and all(5 <= q <= 8 for _, q, _ in s)
