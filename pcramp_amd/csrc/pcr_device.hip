@@ -27,6 +27,7 @@
 #include <stdlib.h>
 #include <string>
 #include <vector>
+#include <chrono>
 #include <algorithm>
 
 #include "../../include/pcramp_hip.h"
@@ -201,7 +202,8 @@ struct HitSink { uint32_t *best; Hit *hits; uint32_t *seq_count; uint32_t *count
 // all on one address -- more than the whole seed scan).
 // best[] holds (pass epoch << 8) | count, so it never needs clearing: values of earlier passes compare lower.
 
-__device__ __noinline__ void record_hit(const HitSink &k, uint32_t seq, uint32_t cand, uint64_t key, uint32_t cnt)
+// (by value: a reference would make every kernel spill its HitSink to scratch at entry -- 64 B per lane of HBM writes)
+__device__ __noinline__ void record_hit(const HitSink k, uint32_t seq, uint32_t cand, uint64_t key, uint32_t cnt)
 {
 	const uint32_t tagged = (k.epoch << 8) | cnt;
 	const uint32_t old = atomicMax(&k.best[(size_t)seq*k.ncand + cand], tagged);
@@ -726,6 +728,8 @@ struct pcr_ctx {
 	DevBuf<uint8_t> arena;
 	const uint4 *d_cand_fwd = nullptr, *d_cand_rc = nullptr; const uint32_t *d_cand_floor = nullptr, *d_tab = nullptr, *d_bias = nullptr;
 	const OligoDev *d_oligos = nullptr;
+	// host-side phase timers (PCRAMP_TIMING=1: printed by pcr_destroy)
+	bool timing = false; double t_host[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint64_t n_timed = 0;
 	// profiling
 	bool prof = false;
 	std::vector<std::pair<hipEvent_t, hipEvent_t> > prof_events;
@@ -733,6 +737,19 @@ struct pcr_ctx {
 };
 
 namespace {
+
+struct HostTimer {
+	pcr_ctx *ctx; int slot; std::chrono::steady_clock::time_point t0;
+	HostTimer(pcr_ctx *c, int s) : ctx(c), slot(s) { if(ctx->timing) t0 = std::chrono::steady_clock::now(); }
+	void next(int s)
+	{
+		if(!ctx->timing) return;
+		const auto t1 = std::chrono::steady_clock::now();
+		ctx->t_host[slot] += std::chrono::duration<double, std::micro>(t1 - t0).count();
+		slot = s; t0 = t1;
+	}
+	~HostTimer() { next(slot); }
+};
 
 int upload_irregular(pcr_ctx *ctx, SeqSet &S)
 {
@@ -890,6 +907,7 @@ int amplify_launch(pcr_ctx *ctx, SeqSet &S, const pcr_pair *pairs, uint32_t n_pa
 		}
 		return PCR_OK;
 	}
+	HostTimer timer(ctx, 4);
 	const float thr2 = a->collect_threshold*a->collect_threshold;                // pcr_assay.cpp:31-32
 	std::vector<OligoDev> ol(2*(size_t)n_pairs);
 	for(uint32_t i = 0;i < n_pairs;++i){
@@ -907,6 +925,7 @@ int amplify_launch(pcr_ctx *ctx, SeqSet &S, const pcr_pair *pairs, uint32_t n_pa
 		HIP_TRY(hipMemsetAsync(d_rf, 0, bits_bytes, ctx->stream));
 	}
 	if((rc = vec_ok ? st.ship(d_fr, bits_bytes, d_rf, bits_bytes) : st.ship()) != PCR_OK) return rc;
+	timer.next(5);
 	const uint32_t mask_words = (2*n_pairs + 31)/32;
 	if((rc = ctx->mask.ensure((size_t)S.n_slots*mask_words)) != PCR_OK) return rc;
 	if((rc = ctx->status.ensure(1)) != PCR_OK) return rc;
@@ -1012,6 +1031,7 @@ pcr_ctx *pcr_create(int device, void *hip_stream, const pcr_params *params)
 	}
 	if(params){ ctx->params = *params; }
 	else{ ctx->params.pack_max_degen = 256; ctx->params.pack_min_gc = 0.0f; ctx->params.pack_max_gc = 1.0f; }
+	if(const char *v = getenv("PCRAMP_TIMING")) ctx->timing = v[0] == '1';
 	if(const char *v = getenv("PCRAMP_SCAN")){ if(v[0] == '1') ctx->scan_version = 1; else if(v[0] == '2') ctx->scan_version = 2; }   // A/B: 1 = popcount scan, 2 = bit-sliced only
 	ctx->filt.max_degen = ctx->params.pack_max_degen;
 	ctx->filt.set_gc(ctx->params.pack_min_gc, ctx->params.pack_max_gc);
@@ -1040,6 +1060,11 @@ void pcr_destroy(pcr_ctx *ctx)
 	if(!ctx) return;
 	(void)hipSetDevice(ctx->device);
 	(void)hipStreamSynchronize(ctx->stream);
+	if(ctx->timing && ctx->n_timed){
+		const double n = (double)ctx->n_timed;
+		fprintf(stderr, "[pcramp] host us/pass: plan %.1f  stage %.1f  launch %.1f  wait %.1f | amplify prep %.1f  launch %.1f  (%llu passes)\n",
+			ctx->t_host[0]/n, ctx->t_host[1]/n, ctx->t_host[2]/n, ctx->t_host[3]/n, ctx->t_host[4]/n, ctx->t_host[5]/n, (unsigned long long)ctx->n_timed);
+	}
 	for(auto &pr : ctx->prof_events){ (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
 	for(int s = 0;s < 2;++s) ctx->sets[s].release();
 	ctx->cand_fwd.release(); ctx->cand_rc.release(); ctx->cand_floor.release(); ctx->best.release();
@@ -1230,6 +1255,8 @@ int pcr_select_words(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_
 	SeqSet &S = ctx->sets[which];
 	S.have_db = false; S.n_entries = 0;
 	if(n_entries_out) *n_entries_out = 0;
+	HostTimer timer(ctx, 0);
+	if(ctx->timing) ++ctx->n_timed;
 	std::vector<pcrhost::Candidate> cand;
 	pcrhost::build_candidates((const uint64_t *)pairs, n_pairs, optimize_5 != 0, optimize_3 != 0, threshold, cand);
 	const uint32_t ncand = (uint32_t)cand.size();
@@ -1267,10 +1294,14 @@ int pcr_select_words(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_
 	SeedTables ST; memset(&ST, 0, sizeof(ST));
 	size_t n_seeds = seeds.size();
 	if(!or_seed.empty()){
-		std::stable_sort(seeds.begin(), seeds.end(), [](const pcrhost::Seed &a, const pcrhost::Seed &b){
-			if(a.q != b.q) return a.q < b.q;
-			return a.code < b.code;
-		});
+		{   // order by (q, code), generation order within a code: sort packed keys, then permute
+			std::vector<uint64_t> keys(seeds.size());
+			for(size_t i = 0;i < seeds.size();++i) keys[i] = ((uint64_t)seeds[i].q << 56) | ((uint64_t)seeds[i].code << 24) | (uint64_t)i;
+			std::sort(keys.begin(), keys.end());
+			std::vector<pcrhost::Seed> sorted(seeds.size());
+			for(size_t i = 0;i < keys.size();++i) sorted[i] = seeds[keys[i] & 0xFFFFFFu];
+			seeds.swap(sorted);
+		}
 		uint32_t q_mask = 0;
 		for(const pcrhost::Seed &sd : seeds) q_mask |= 1u << (sd.q - 5);
 		uint32_t words = 0;
@@ -1330,6 +1361,7 @@ int pcr_select_words(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_
 		bytes += (tab_plain.tab.size() + tab_plain.bias.size() + or_plain.size() + 256)*sizeof(uint32_t);
 		bytes += (tab_seedset.tab.size() + tab_seedset.bias.size() + or_seed.size() + 256)*sizeof(uint32_t);
 		bytes += (image.size() + 64)*sizeof(uint32_t);
+		timer.next(1);
 		Stager st(ctx);
 		if((rc = st.begin(bytes)) != PCR_OK) return rc;
 		ctx->d_cand_fwd = st.put(hf.data(), ncand);
@@ -1354,6 +1386,7 @@ int pcr_select_words(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_
 		if((rc = st.ship(S.ctrl.p, (8 + 2*(size_t)S.n)*sizeof(uint32_t))) != PCR_OK) return rc;
 	}
 
+	timer.next(2);
 	uint32_t h_counters[4];
 	if((rc = S.touched.ensure(S.n)) != PCR_OK) return rc;
 	uint32_t *const d_counters = S.ctrl.p, *const d_seq_count = S.ctrl.p + 8;
@@ -1427,7 +1460,9 @@ int pcr_select_words(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_
 		// the only host synchronisation of the pass: overflow flag + DB size, through the mapped mailbox
 		hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, ctx->stream, d_counters, ctx->mail_dev, ++ctx->mail_seq);
 		HIP_TRY(hipGetLastError());
+		timer.next(3);
 		if((rc = mail_wait(ctx, ctx->mail_seq, h_counters)) != PCR_OK) return rc;
+		timer.next(2);
 		S.db_cap = cap; S.n_slots = n_slots;
 		if(!(h_counters[0] & 1u)) break;
 		// some sequence collected more hits than its bucket holds: grow the buckets and redo the pass

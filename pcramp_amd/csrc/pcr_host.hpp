@@ -386,22 +386,22 @@ struct Candidate {
 inline void build_candidates(const uint64_t *pairs /* n x {F[2],R[2]} */, uint32_t n_pairs, bool opt5, bool opt3,
 	float threshold, std::vector<Candidate> &out)
 {
+	auto emit = [&out, threshold](const Planes &w){
+		Candidate c;
+		c.fwd = w;
+		c.rc = planes_revcomp(w);
+		c.floor_ = (unsigned)((float)(unsigned)planes_size(w)*threshold);
+		out.push_back(c);
+	};
+	out.reserve(out.size() + 2*(size_t)n_pairs*((opt5 || opt3) ? 8 : 1));
 	for(uint32_t i = 0;i < n_pairs;++i){
 		for(int o = 0;o < 2;++o){
 			const Planes base = planes_of_word(pairs + 4*i + 2*o);
-			std::vector<Planes> v;
-			v.push_back(base);
+			emit(base);
 			if(opt5 || opt3){
 				const int cs = planes_start(base), ce = planes_stop(base);
-				if(opt5 && cs > 0){ Planes t = base; for(int j = 0;j < cs;++j){ t = planes_shift_left(t); v.push_back(t); } }
-				if(opt3 && ce < 31){ Planes t = base; for(int j = ce;j < 31;++j){ t = planes_shift_right(t); v.push_back(t); } }
-			}
-			for(size_t k = 0;k < v.size();++k){
-				Candidate c;
-				c.fwd = v[k];
-				c.rc = planes_revcomp(v[k]);
-				c.floor_ = (unsigned)((float)(unsigned)planes_size(v[k])*threshold);
-				out.push_back(c);
+				if(opt5 && cs > 0){ Planes t = base; for(int j = 0;j < cs;++j){ t = planes_shift_left(t); emit(t); } }
+				if(opt3 && ce < 31){ Planes t = base; for(int j = ce;j < 31;++j){ t = planes_shift_right(t); emit(t); } }
 			}
 		}
 	}
@@ -474,44 +474,57 @@ enum { MIN_SEED_Q = 5, MAX_SEED_Q = 8, MAX_SEED_EXPANSION = 16 };
 // Appends the seeds of one orientation; returns false (nothing appended) if it cannot be seeded.
 inline bool orientation_seeds(const Planes &m, uint32_t floor_, uint32_t orient, std::vector<Seed> &out)
 {
-	const int size = planes_size(m);
+	const uint32_t occ = m.a | m.c | m.g | m.t;
+	const int size = __builtin_popcount(occ);
 	if(size == 0 || floor_ == 0 || floor_ > (uint32_t)size) return floor_ > (uint32_t)size;   // dead orientation: trivially "seeded" with no seeds
 	const int k = size - (int)floor_;
 	const int nblk = k + 1;
 	if(size/nblk < MIN_SEED_Q) return false;
-	// occupied slots in order (oligos are contiguous, but do not rely on it)
-	int slots[32], n = 0;
-	for(int s = 0;s < 32;++s){ if(planes_nibble(m, s)) slots[n++] = s; }
-	for(int s = 1;s < n;++s){ if(slots[s] != slots[s - 1] + 1) return false; }       // holes: leave it to the bit-sliced scan
+	const int first = __builtin_ctz(occ);
+	if((occ >> first) != ((size == 32) ? 0xFFFFFFFFu : ((1u << size) - 1u))) return false;   // holes: leave it to the bit-sliced scan
+	// slots holding more than one base, and the 2-bit code planes of the others (A,C,G,T = 0..3)
+	const uint32_t multi = (m.a & m.c) | (m.a & m.g) | (m.a & m.t) | (m.c & m.g) | (m.c & m.t) | (m.g & m.t);
+	const uint32_t lo = m.c | m.t, hi = m.g | m.t;
 	const size_t first_out = out.size();
-	int pos = 0;
+	int pos = first;                                          // slot of the block's first base
 	for(int b = 0;b < nblk;++b){
 		const int len = size/nblk + ((b < size % nblk) ? 1 : 0);
 		const int q = std::min<int>(len, MAX_SEED_Q);
-		// the q-subwindow of the block with the fewest expansions
+		const uint32_t blk_mask = (len == 32) ? 0xFFFFFFFFu : (((1u << len) - 1u) << pos);
+		if(!(multi & blk_mask)){
+			// plain block: its first q bases, one code
+			uint32_t code = 0;
+			for(int j = 0;j < q;++j) code |= ((((lo >> (pos + j)) & 1u) | (((hi >> (pos + j)) & 1u) << 1)) << (2*j));
+			Seed sd; sd.code = code; sd.orient = (uint16_t)orient; sd.q = (uint8_t)q; sd.off = (uint8_t)pos;
+			out.push_back(sd);
+			pos += len;
+			continue;
+		}
+		// IUPAC slots in the block: the q-subwindow with the fewest expansions (first one on ties)
+		unsigned mult[32];
+		for(int j = 0;j < len;++j) mult[j] = (unsigned)__builtin_popcount(planes_nibble(m, pos + j));
 		int best_w = -1; unsigned best_e = ~0u;
 		for(int w = 0;w + q <= len;++w){
 			unsigned e = 1;
-			for(int j = 0;j < q;++j) e *= (unsigned)__builtin_popcount(planes_nibble(m, slots[pos + w + j]));
+			for(int j = 0;j < q;++j) e *= mult[w + j];
 			if(e < best_e){ best_e = e; best_w = w; }
 		}
 		if(best_e > MAX_SEED_EXPANSION){ out.resize(first_out); return false; }
-		// enumerate the member codes (A=0,C=1,G=2,T=3; first base in the LOW bits)
+		// enumerate the member codes (first base in the LOW bits)
 		unsigned idx[MAX_SEED_Q]; for(int j = 0;j < q;++j) idx[j] = 0;
 		while(true){
-			uint32_t code = 0; bool ok = true;
+			uint32_t code = 0;
 			for(int j = 0;j < q;++j){
-				const unsigned set = planes_nibble(m, slots[pos + best_w + j]);
-				unsigned seen = 0, base = 4;
+				const unsigned set = planes_nibble(m, pos + best_w + j);
+				unsigned seen = 0, base = 0;
 				for(unsigned bb = 0;bb < 4;++bb){ if(set & (1u << bb)){ if(seen == idx[j]){ base = bb; break; } ++seen; } }
-				if(base == 4){ ok = false; break; }
 				code |= base << (2*j);
 			}
-			if(ok){ Seed sd; sd.code = code; sd.orient = (uint16_t)orient; sd.q = (uint8_t)q; sd.off = (uint8_t)slots[pos + best_w]; out.push_back(sd); }
+			Seed sd; sd.code = code; sd.orient = (uint16_t)orient; sd.q = (uint8_t)q; sd.off = (uint8_t)(pos + best_w);
+			out.push_back(sd);
 			int j = 0;
 			for(;j < q;++j){
-				const unsigned cnt = (unsigned)__builtin_popcount(planes_nibble(m, slots[pos + best_w + j]));
-				if(++idx[j] < cnt) break;
+				if(++idx[j] < mult[best_w + j]) break;
 				idx[j] = 0;
 			}
 			if(j == q) break;

@@ -12,6 +12,12 @@ import re
 import sys
 
 
+def newest(pattern):
+    """gpurun merges every call's files into the same directory: take the latest run's."""
+    import os
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
 def short(name):
     name = re.sub(r"\(anonymous namespace\)::", "", name)
     name = re.sub(r"^void ", "", name)
@@ -20,7 +26,7 @@ def short(name):
 
 
 def stats(d):
-    f = glob.glob(d + "/*/*kernel_stats.csv")[0]
+    f = newest(d + "/*/*kernel_stats.csv")
     rows = list(csv.DictReader(open(f)))
     print("| kernel | calls | avg us | total ms | % |")
     print("|---|---|---|---|---|")
@@ -32,7 +38,7 @@ def stats(d):
 def pmc(dirs):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for d in dirs:
-        f = glob.glob(d + "/*/*counter_collection.csv")[0]
+        f = newest(d + "/*/*counter_collection.csv")
         for r in csv.DictReader(open(f)):
             agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     print("| kernel | launches | FETCH_SIZE KB/launch (raw) | fetch MB/launch (x2 gfx950 correction) | WRITE_SIZE KB/launch | HBM MB/launch |")
