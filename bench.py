@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--random-primers", action="store_true", help="diagnostic: primers unrelated to the targets (no hits)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--separate-calls", action="store_true",
+                    help="pcr_select_words + pcr_amplify_device per step (host wait between them) instead of pcr_screen_device")
     ap.add_argument("--target-threshold", type=float, default=1.0,
                     help="--target.threshold of the reference (pcramp.h:39 default 1.0)")
     ap.add_argument("--search-multiplier", type=float, default=0.9,
@@ -129,10 +131,15 @@ def main():
     def step():
         if timing:
             t_a = time.perf_counter()
-        scr.select_words(pa, select_thr, 18, count=False)
+        if args.separate_calls:
+            scr.select_words(pa, select_thr, 18, count=False)
         if timing:
             t_b = time.perf_counter()
-        scr.amplify_device(pa, p_fr, p_rf, thr_t, thr_t, 80, 200, False)
+        if args.separate_calls:
+            scr.amplify_device(pa, p_fr, p_rf, thr_t, thr_t, 80, 200, False)
+        else:
+            # one optimiser iteration's DB build + find_target_match, enqueued without a host wait
+            scr.screen_device(pa, select_thr, p_fr, p_rf, thr_t, thr_t, 80, 200, False, 18)
         if timing:
             t_c = time.perf_counter()
             host_t[0] += t_b - t_a
@@ -142,6 +149,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    scr.synchronize()
     torch.cuda.synchronize()
     scr.profile(True)
     scr.profile_read(reset=True)
@@ -151,6 +159,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    scr.synchronize()          # inspects the counters of the passes still in flight (replays on bucket overflow)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -121,6 +121,18 @@ int pcr_amplify(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 int pcr_amplify_device(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_pairs,
 	const pcr_amplify_args *args, uint64_t *d_bits_fr, uint64_t *d_bits_rf);
 
+/* pcr_select_words followed by pcr_amplify_device for the same batch -- one optimiser iteration's
+ * DB build + find_target_match (main.cpp:644-691 then pcr_assay.cpp:544-578) -- ENQUEUED on the
+ * handle's stream without any host wait, so the host plans pass i+1 while pass i runs.
+ * The per-sequence bucket overflow that pcr_select_words handles by retrying cannot be seen
+ * before the pass has run: the device buffers are final only after pcr_synchronize() (or any other
+ * entry point of the same handle) has returned PCR_OK -- that call inspects the counters of every
+ * enqueued pass and, if a pass overflowed, replays it and the later ones with larger buckets into
+ * the same buffers.  At most 6 passes are kept in flight. */
+int pcr_screen_device(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_pairs,
+	int optimize_5, int optimize_3, float select_threshold, uint32_t min_oligo_length,
+	const pcr_amplify_args *args, uint64_t *d_bits_fr, uint64_t *d_bits_rf);
+
 /* compute_coverage's weight sum (pcr_assay.cpp:280-301) from gathered orientation bitsets:
  * ascending index over bits_fr, then ascending index over bits_rf & ~bits_fr, accumulated in
  * double; n = number of sequences, weights[n].  Pure host arithmetic (no device needed). */

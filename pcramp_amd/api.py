@@ -74,7 +74,7 @@ _LIB = None
 # every symbol include/pcramp_hip.h declares
 ABI_SYMBOLS = [
     "pcr_last_error", "pcr_create", "pcr_destroy", "pcr_load_sequences", "pcr_set_active", "pcr_split",
-    "pcr_select_words", "pcr_get_entries", "pcr_amplify", "pcr_amplify_device", "pcr_coverage_from_bits",
+    "pcr_select_words", "pcr_get_entries", "pcr_amplify", "pcr_amplify_device", "pcr_screen_device", "pcr_coverage_from_bits",
     "pcr_weighted_coverage", "pcr_num_sequences", "pcr_bitset_words", "pcr_profile_enable", "pcr_profile_read",
     "pcr_synchronize", "pcr_host_irregular_words", "pcr_host_window_valid", "pcr_host_candidates",
     "pcr_host_orientation_seeds",
@@ -130,6 +130,8 @@ def load_library():
     L.pcr_host_window_valid.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(_Params), C.c_void_p]
     L.pcr_host_candidates.restype = C.c_int64
     L.pcr_host_candidates.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_uint64]
+    L.pcr_screen_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_float, C.c_uint32,
+                                    C.POINTER(AmplifyArgs), C.c_void_p, C.c_void_p]
     L.pcr_host_orientation_seeds.restype = C.c_int64
     L.pcr_host_orientation_seeds.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
     _LIB = L
@@ -313,6 +315,17 @@ class Screener:
         args = AmplifyArgs(collect_threshold, ident_threshold, amp_min, amp_max, int(use_taq_mama))
         self._check(self.L.pcr_amplify_device(self.h, which, a.ctypes.data, a.shape[0], C.byref(args),
                                               C.c_void_p(d_fr_ptr), C.c_void_p(d_rf_ptr)))
+
+    def screen_device(self, pairs, select_threshold, d_fr_ptr, d_rf_ptr, collect_threshold, ident_threshold,
+                      amp_min=80, amp_max=200, use_taq_mama=False, min_oligo_length=18, optimize_5=False,
+                      optimize_3=False, which=TARGET):
+        """select_words + amplify_device for one batch, enqueued without a host wait; the device
+        buffers are final after synchronize()."""
+        a = pairs if isinstance(pairs, np.ndarray) else W.pairs_array(pairs)
+        args = AmplifyArgs(collect_threshold, ident_threshold, amp_min, amp_max, int(use_taq_mama))
+        self._check(self.L.pcr_screen_device(self.h, which, a.ctypes.data, a.shape[0], int(optimize_5), int(optimize_3),
+                                             select_threshold, min_oligo_length, C.byref(args),
+                                             C.c_void_p(d_fr_ptr), C.c_void_p(d_rf_ptr)))
 
     # -- the two reference evaluations, with Options-style arguments
     def find_target_match(self, pairs, target_threshold=1.0, amp_min=80, amp_max=200, use_taq_mama=False, which=TARGET):

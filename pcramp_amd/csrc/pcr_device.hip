@@ -512,14 +512,14 @@ __device__ __forceinline__ bool db_slot(uint32_t g, uint32_t n, uint32_t cap, co
 // step, the 64 compare results leave as one ballot.  (One lane per DB slot walked the oligo list serially:
 // with a handful of filled slots per sequence that was a chain of dependent scalar loads, 20 us at C2.)
 constexpr int MATCH_WAVES = 4;
-__global__ __launch_bounds__(64*MATCH_WAVES) void k_match(const DevEntry *__restrict__ db, uint32_t n_touched, uint32_t cap,
+__global__ __launch_bounds__(64*MATCH_WAVES) void k_match(const DevEntry *__restrict__ db, uint32_t n_touched, const uint32_t *__restrict__ n_touched_dev, uint32_t cap,
 	const uint32_t *__restrict__ touched, const uint32_t *__restrict__ seg_hi, const OligoDev *__restrict__ oligos, uint32_t n_oligo,
 	uint32_t mask_words, uint32_t *__restrict__ mask, uint32_t *__restrict__ status)
 {
 	if(blockIdx.x == 0 && threadIdx.x == 0 && status) status[0] = 0;
-	const uint32_t t_idx = blockIdx.x*MATCH_WAVES + (threadIdx.x >> 6);
-	if(t_idx >= n_touched) return;
+	if(n_touched_dev) n_touched = *n_touched_dev;                // asynchronous passes: the host does not know it yet
 	const uint32_t lane = threadIdx.x & 63u, sub = lane >> 5, ol = lane & 31u;
+	for(uint32_t t_idx = blockIdx.x*MATCH_WAVES + (threadIdx.x >> 6);t_idx < n_touched;t_idx += gridDim.x*MATCH_WAVES){
 	const uint32_t seq = touched[t_idx];
 	const uint32_t lo = seq*cap, n_e = seg_hi[seq] - lo;         // filled slots [lo, seg_hi[seq])
 	for(uint32_t e0 = 0;e0 < n_e;e0 += 2){
@@ -537,6 +537,7 @@ __global__ __launch_bounds__(64*MATCH_WAVES) void k_match(const DevEntry *__rest
 			const uint64_t bal = __ballot(ok);
 			if(have && ol == 0) mask[(size_t)i*mask_words + mw] = sub ? (uint32_t)(bal >> 32) : (uint32_t)bal;
 		}
+	}
 	}
 }
 
@@ -584,18 +585,19 @@ __device__ bool has_split(const uint4 *__restrict__ planes, uint64_t base, int32
 // One lane per plus-strand DB entry i; it walks the later entries j of the same sequence
 // (sorted by WordMatch::loc, as assay.h:48-61) and, for every assay pair matched by both,
 // applies find_amplicon_match (pcr_assay.cpp:338-441) and the identity test.
-__global__ void k_pair(const DevEntry *__restrict__ db, uint32_t n, uint32_t cap, const uint32_t *__restrict__ touched,
+__global__ void k_pair(const DevEntry *__restrict__ db, uint32_t n, const uint32_t *__restrict__ n_touched_dev, uint32_t cap, const uint32_t *__restrict__ touched,
 	const uint32_t *__restrict__ seg_hi, const uint32_t *__restrict__ mask, uint32_t mask_words, const OligoDev *__restrict__ oligos, uint32_t n_pairs,
 	const uint4 *__restrict__ planes, const uint64_t *__restrict__ blk_off, const uint64_t *__restrict__ len,
 	const uint8_t *__restrict__ active, int32_t amp_min, int32_t amp_max, float ident_thr, int use_taq,
 	uint64_t *__restrict__ bits_fr, uint64_t *__restrict__ bits_rf, uint64_t bit_words, uint32_t *__restrict__ status)
 {
-	const uint32_t t = blockIdx.x*blockDim.x + threadIdx.x;
+	if(n_touched_dev) n = (*n_touched_dev)*cap;                                  // asynchronous passes
+	for(uint32_t t = blockIdx.x*blockDim.x + threadIdx.x;t < n;t += gridDim.x*blockDim.x){
 	uint32_t i;
-	if(!db_slot(t, n, cap, touched, seg_hi, i)) return;
+	if(!db_slot(t, n, cap, touched, seg_hi, i)) continue;
 	const DevEntry ei = db[i];
-	if(ei.strand != 1) return;
-	if(!active[ei.seq]) return;                                                  // optimize.cpp:281
+	if(ei.strand != 1) continue;
+	if(!active[ei.seq]) continue;                                                // optimize.cpp:281
 	const uint32_t hi = seg_hi[ei.seq];
 	const int32_t L = (int32_t)len[ei.seq];
 	const uint64_t base = blk_off[ei.seq];
@@ -640,12 +642,15 @@ __global__ void k_pair(const DevEntry *__restrict__ db, uint32_t n, uint32_t cap
 			}
 		}
 	}
+	}
 }
 
 #include "pcr_sw.inc"
 #include "pcr_thermo.inc"
 
 // ============================================================================== host state
+constexpr uint32_t N_TOUCHED_UNKNOWN = 0xFFFFFFFFu;
+
 template<class T> struct DevBuf {
 	T *p = nullptr; size_t cap = 0;
 	int ensure(size_t n)
@@ -721,10 +726,22 @@ struct pcr_ctx {
 	uint32_t epoch = 0;         // pass counter tagging best[] (see HitSink)
 	uint32_t *best_seen = nullptr;
 	// pinned staging for the small per-call host->device payload (candidates, tables, oligos): one async copy
-	uint8_t *stage = nullptr, *stage_dev = nullptr; size_t stage_cap = 0; hipEvent_t stage_done = nullptr; bool stage_busy = false;
+	// ring of host-mapped staging buffers: a slot is rewritten only after the k_stage that read it has run,
+	// so the host can prepare the next pass while the previous one is still on the GPU
+	static constexpr int STAGE_RING = 4;
+	struct StageSlot { uint8_t *host = nullptr, *dev = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool busy = false; };
+	StageSlot stage[STAGE_RING]; int stage_next = 0;
 	struct Mail { volatile uint32_t counters[4]; volatile uint32_t seq; uint32_t pad[11]; };
-	Mail *mail = nullptr, *mail_dev = nullptr;   // host-mapped: k_publish writes it, the host spins on seq
+	static constexpr uint32_t MAIL_RING = 8;
+	Mail *mail = nullptr, *mail_dev = nullptr;   // host-mapped ring (slot = seq % MAIL_RING): k_publish writes it, the host spins on seq
 	uint32_t mail_seq = 0;
+	// passes enqueued by pcr_screen_device whose counters have not been looked at yet (pcr_synchronize / any
+	// other entry point drains them; a bucket overflow found then replays the passes synchronously)
+	struct Pending {
+		uint32_t seq; int which; std::vector<pcr_pair> pairs; int opt5, opt3; float thr; uint32_t min_len;
+		pcr_amplify_args args; uint64_t *d_fr, *d_rf;
+	};
+	std::vector<Pending> pending;
 	DevBuf<uint8_t> arena;
 	const uint4 *d_cand_fwd = nullptr, *d_cand_rc = nullptr; const uint32_t *d_cand_floor = nullptr, *d_tab = nullptr, *d_bias = nullptr;
 	const OligoDev *d_oligos = nullptr;
@@ -737,6 +754,9 @@ struct pcr_ctx {
 };
 
 namespace {
+
+int drain(pcr_ctx *ctx);
+#define DRAIN(ctx) do{ if(!(ctx)->pending.empty()){ const int drc_ = drain(ctx); if(drc_ != PCR_OK) return drc_; } }while(0)
 
 struct HostTimer {
 	pcr_ctx *ctx; int slot; std::chrono::steady_clock::time_point t0;
@@ -825,17 +845,20 @@ __global__ void k_stage(const uint4 *__restrict__ src, uint4 *__restrict__ dst, 
 struct Stager {
 	pcr_ctx *ctx; size_t used = 0;
 	explicit Stager(pcr_ctx *c) : ctx(c) {}
+	pcr_ctx::StageSlot *slot = nullptr;
 	int begin(size_t bytes)
 	{
-		if(ctx->stage_busy){ HIP_TRY(hipEventSynchronize(ctx->stage_done)); ctx->stage_busy = false; }
-		if(bytes > ctx->stage_cap){
-			if(ctx->stage){ (void)hipHostFree(ctx->stage); ctx->stage = nullptr; ctx->stage_cap = 0; }
+		slot = &ctx->stage[ctx->stage_next];
+		ctx->stage_next = (ctx->stage_next + 1) % pcr_ctx::STAGE_RING;
+		if(slot->busy){ HIP_TRY(hipEventSynchronize(slot->done)); slot->busy = false; }
+		if(bytes > slot->cap){
+			if(slot->host){ (void)hipHostFree(slot->host); slot->host = nullptr; slot->cap = 0; }
 			const size_t want = std::max<size_t>(bytes*2, 1 << 16);
-			HIP_TRY(hipHostMalloc((void **)&ctx->stage, want, hipHostMallocMapped | hipHostMallocCoherent));
-			HIP_TRY(hipHostGetDevicePointer((void **)&ctx->stage_dev, ctx->stage, 0));
-			ctx->stage_cap = want;
+			HIP_TRY(hipHostMalloc((void **)&slot->host, want, hipHostMallocMapped | hipHostMallocCoherent));
+			HIP_TRY(hipHostGetDevicePointer((void **)&slot->dev, slot->host, 0));
+			slot->cap = want;
 		}
-		if(!ctx->stage_done) HIP_TRY(hipEventCreateWithFlags(&ctx->stage_done, hipEventDisableTiming));
+		if(!slot->done) HIP_TRY(hipEventCreateWithFlags(&slot->done, hipEventDisableTiming));
 		int rc = ctx->arena.ensure(bytes + 256);
 		used = 0;
 		return rc;
@@ -844,7 +867,7 @@ struct Stager {
 	template<class T> T *put(const T *src, size_t n)
 	{
 		used = (used + 15) & ~size_t(15);
-		memcpy(ctx->stage + used, src, n*sizeof(T));
+		memcpy(slot->host + used, src, n*sizeof(T));
 		T *dev = (T *)(ctx->arena.p + used);
 		used += n*sizeof(T);
 		return dev;
@@ -857,12 +880,12 @@ struct Stager {
 		const uint32_t most = std::max(n16, std::max(n0, n1));
 		if(most){
 			const unsigned grid = std::min<unsigned>((most + 255)/256, 512u);
-			hipLaunchKernelGGL(k_stage, dim3(grid), dim3(256), 0, ctx->stream, (const uint4 *)ctx->stage_dev, (uint4 *)ctx->arena.p, n16,
+			hipLaunchKernelGGL(k_stage, dim3(grid), dim3(256), 0, ctx->stream, (const uint4 *)slot->dev, (uint4 *)ctx->arena.p, n16,
 				(uint4 *)z0, n0, (uint4 *)z1, n1);
 			HIP_TRY(hipGetLastError());
 		}
-		HIP_TRY(hipEventRecord(ctx->stage_done, ctx->stream));
-		ctx->stage_busy = true;
+		HIP_TRY(hipEventRecord(slot->done, ctx->stream));
+		slot->busy = true;
 		return PCR_OK;
 	}
 };
@@ -879,18 +902,19 @@ __global__ void k_publish(const uint32_t *__restrict__ counters, pcr_ctx::Mail *
 int mail_wait(pcr_ctx *ctx, uint32_t seq, uint32_t out[4])
 {
 	uint64_t spins = 0;
-	while(__atomic_load_n((const uint32_t *)&ctx->mail->seq, __ATOMIC_ACQUIRE) != seq){
+	pcr_ctx::Mail *const slot = ctx->mail + (seq % pcr_ctx::MAIL_RING);
+	while(__atomic_load_n((const uint32_t *)&slot->seq, __ATOMIC_ACQUIRE) != seq){
 		__builtin_ia32_pause();
 		if((++spins & 0x3FFF) == 0){
 			const hipError_t e = hipStreamQuery(ctx->stream);
 			if(e == hipSuccess){                          // everything drained: the flag must be there now
-				if(__atomic_load_n((const uint32_t *)&ctx->mail->seq, __ATOMIC_ACQUIRE) == seq) break;
+				if(__atomic_load_n((const uint32_t *)&slot->seq, __ATOMIC_ACQUIRE) == seq) break;
 				g_err = "device pass finished without publishing its counters"; return PCR_ERR_DEVICE;
 			}
 			if(e != hipErrorNotReady){ g_err = std::string("device pass failed: ") + hipGetErrorString(e); return PCR_ERR_DEVICE; }
 		}
 	}
-	for(int i = 0;i < 4;++i) out[i] = ctx->mail->counters[i];
+	for(int i = 0;i < 4;++i) out[i] = slot->counters[i];
 	return PCR_OK;
 }
 
@@ -929,14 +953,19 @@ int amplify_launch(pcr_ctx *ctx, SeqSet &S, const pcr_pair *pairs, uint32_t n_pa
 	const uint32_t mask_words = (2*n_pairs + 31)/32;
 	if((rc = ctx->mask.ensure((size_t)S.n_slots*mask_words)) != PCR_OK) return rc;
 	if((rc = ctx->status.ensure(1)) != PCR_OK) return rc;
-	const unsigned threads = 128;
-	const uint32_t n_db = S.n_touched*S.db_cap;
-	const unsigned grid = (n_db + threads - 1)/threads;
+	// the number of touched sequences: known to the host after a synchronous select, read on the device
+	// (conservative grids, grid-stride loops) after an asynchronous one
+	const bool dev_n = S.n_touched == N_TOUCHED_UNKNOWN;
+	const uint32_t *n_dev = dev_n ? S.ctrl.p + 3 : nullptr;
+	const uint32_t n_t = dev_n ? 0u : S.n_touched, n_db = n_t*S.db_cap;
+	const unsigned threads = dev_n ? 256 : 128;
+	const unsigned grid = dev_n ? (unsigned)std::min<uint64_t>(((uint64_t)S.n*S.db_cap + threads - 1)/threads, 1024) : (n_db + threads - 1)/threads;
+	const unsigned mgrid = dev_n ? std::min<unsigned>((S.n + MATCH_WAVES - 1)/MATCH_WAVES, 1024u) : (n_t + MATCH_WAVES - 1)/MATCH_WAVES;
 	// k_match also clears the status word (it runs before k_pair in stream order)
-	hipLaunchKernelGGL(k_match, dim3((S.n_touched + MATCH_WAVES - 1)/MATCH_WAVES), dim3(64*MATCH_WAVES), 0, ctx->stream, S.db.p, S.n_touched, S.db_cap,
+	hipLaunchKernelGGL(k_match, dim3(mgrid), dim3(64*MATCH_WAVES), 0, ctx->stream, S.db.p, n_t, n_dev, S.db_cap,
 		S.touched.p, S.d_seg_hi, ctx->d_oligos, 2*n_pairs, mask_words, ctx->mask.p, ctx->status.p);
 	HIP_TRY(hipGetLastError());
-	hipLaunchKernelGGL(k_pair, dim3(grid), dim3(threads), 0, ctx->stream, S.db.p, n_db, S.db_cap, S.touched.p, S.d_seg_hi, ctx->mask.p,
+	hipLaunchKernelGGL(k_pair, dim3(grid), dim3(threads), 0, ctx->stream, S.db.p, n_db, n_dev, S.db_cap, S.touched.p, S.d_seg_hi, ctx->mask.p,
 		mask_words, ctx->d_oligos, n_pairs, S.planes.p, S.d_blk_off.p, S.d_len.p, S.d_active.p, a->amp_min, a->amp_max,
 		a->ident_threshold, a->use_taq_mama, d_fr, d_rf, words, ctx->status.p);
 	HIP_TRY(hipGetLastError());
@@ -1047,11 +1076,11 @@ pcr_ctx *pcr_create(int device, void *hip_stream, const pcr_params *params)
 	   hipMemcpyToSymbol(HIP_SYMBOL(thermo::c_wc), PCR_WC, sizeof(PCR_WC)) != hipSuccess){
 		g_err = "pcr_create: hipMemcpyToSymbol failed"; delete ctx; return nullptr;
 	}
-	if(hipHostMalloc((void **)&ctx->mail, sizeof(pcr_ctx::Mail), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+	if(hipHostMalloc((void **)&ctx->mail, sizeof(pcr_ctx::Mail)*pcr_ctx::MAIL_RING, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
 	   hipHostGetDevicePointer((void **)&ctx->mail_dev, ctx->mail, 0) != hipSuccess){
 		g_err = "pcr_create: mapped host allocation failed"; if(ctx->mail) (void)hipHostFree(ctx->mail); delete ctx; return nullptr;
 	}
-	memset((void *)ctx->mail, 0, sizeof(pcr_ctx::Mail));
+	memset((void *)ctx->mail, 0, sizeof(pcr_ctx::Mail)*pcr_ctx::MAIL_RING);
 	return ctx;
 }
 
@@ -1060,6 +1089,7 @@ void pcr_destroy(pcr_ctx *ctx)
 	if(!ctx) return;
 	(void)hipSetDevice(ctx->device);
 	(void)hipStreamSynchronize(ctx->stream);
+	ctx->pending.clear();
 	if(ctx->timing && ctx->n_timed){
 		const double n = (double)ctx->n_timed;
 		fprintf(stderr, "[pcramp] host us/pass: plan %.1f  stage %.1f  launch %.1f  wait %.1f | amplify prep %.1f  launch %.1f  (%llu passes)\n",
@@ -1070,9 +1100,8 @@ void pcr_destroy(pcr_ctx *ctx)
 	ctx->cand_fwd.release(); ctx->cand_rc.release(); ctx->cand_floor.release(); ctx->best.release();
 	ctx->counters.release(); ctx->mask.release(); ctx->status.release(); ctx->hits.release();
 	ctx->bits_fr.release(); ctx->bits_rf.release(); ctx->arena.release(); ctx->fin_scratch.release();
-	if(ctx->stage) (void)hipHostFree(ctx->stage);
+	for(auto &sl : ctx->stage){ if(sl.host) (void)hipHostFree(sl.host); if(sl.done) (void)hipEventDestroy(sl.done); }
 	if(ctx->mail) (void)hipHostFree(ctx->mail);
-	if(ctx->stage_done) (void)hipEventDestroy(ctx->stage_done);
 	ctx->oligos.release(); ctx->tab.release(); ctx->bias.release(); ctx->sw_jobs.release(); ctx->sw_out.release(); ctx->sw_q.release(); ctx->sw_qlen.release(); ctx->sw_t.release(); ctx->entry_codes.release(); ctx->entry_lens.release(); ctx->amp_recs.release(); ctx->bg_pairs.release(); ctx->th_jobs.release(); ctx->th_out.release(); ctx->th_dg.release(); ctx->th_scratch_i.release(); ctx->th_scratch_s.release();
 	if(ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
@@ -1084,6 +1113,8 @@ uint64_t pcr_bitset_words(pcr_ctx *ctx, pcr_set which) { return ctx ? (ctx->sets
 int pcr_synchronize(pcr_ctx *ctx)
 {
 	if(!ctx){ g_err = "null ctx"; return PCR_ERR_ARG; }
+	HIP_TRY(hipSetDevice(ctx->device));
+	DRAIN(ctx);
 	HIP_TRY(hipStreamSynchronize(ctx->stream));
 	return PCR_OK;
 }
@@ -1094,6 +1125,7 @@ int pcr_load_sequences(pcr_ctx *ctx, pcr_set which, const uint8_t *packed4, cons
 	if(!ctx || (which != PCR_SET_TARGET && which != PCR_SET_BACKGROUND) || (n && (!packed4 || !byte_offsets || !lengths))){
 		g_err = "pcr_load_sequences: bad argument"; return PCR_ERR_ARG;
 	}
+	DRAIN(ctx);
 	if(n >= (1u << 24)){ g_err = "pcr_load_sequences: at most 2^24-1 sequences per GPU shard"; return PCR_ERR_CAPACITY; }
 	HIP_TRY(hipSetDevice(ctx->device));
 	SeqSet &S = ctx->sets[which];
@@ -1206,6 +1238,7 @@ int pcr_load_sequences(pcr_ctx *ctx, pcr_set which, const uint8_t *packed4, cons
 int pcr_set_active(pcr_ctx *ctx, pcr_set which, const uint8_t *active)
 {
 	if(!ctx || !active){ g_err = "pcr_set_active: bad argument"; return PCR_ERR_ARG; }
+	DRAIN(ctx);
 	SeqSet &S = ctx->sets[which];
 	for(uint32_t i = 0;i < S.n;++i) S.active[i] = active[i] ? 1 : 0;
 	if(S.n){
@@ -1218,6 +1251,7 @@ int pcr_set_active(pcr_ctx *ctx, pcr_set which, const uint8_t *active)
 int pcr_split(pcr_ctx *ctx, pcr_set which, uint32_t seq, uint64_t pos)
 {
 	if(!ctx){ g_err = "null ctx"; return PCR_ERR_ARG; }
+	DRAIN(ctx);
 	SeqSet &S = ctx->sets[which];
 	if(seq >= S.n || pos >= S.len[seq]){ g_err = "pcr_split: out of range"; return PCR_ERR_ARG; }
 	uint8_t &v = S.packed[seq][pos >> 1];
@@ -1246,8 +1280,14 @@ int pcr_split(pcr_ctx *ctx, pcr_set which, uint32_t seq, uint64_t pos)
 	return upload_irregular(ctx, S);
 }
 
-int pcr_select_words(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_pairs, int optimize_5, int optimize_3,
-	float threshold, uint32_t min_oligo_length, uint64_t *n_entries_out)
+} // extern "C"
+
+namespace {
+
+// pcr_select_words proper.  async: enqueue one attempt and return without looking at the counters
+// (pcr_screen_device; the caller records the pass as pending).
+int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_pairs, int optimize_5, int optimize_3,
+	float threshold, uint32_t min_oligo_length, uint64_t *n_entries_out, bool async)
 {
 	if(!ctx || (n_pairs && !pairs)){ g_err = "pcr_select_words: bad argument"; return PCR_ERR_ARG; }
 	if(min_oligo_length < 1 || min_oligo_length > 32){ g_err = "pcr_select_words: min_oligo_length must be in [1,32]"; return PCR_ERR_ARG; }
@@ -1260,7 +1300,7 @@ int pcr_select_words(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_
 	std::vector<pcrhost::Candidate> cand;
 	pcrhost::build_candidates((const uint64_t *)pairs, n_pairs, optimize_5 != 0, optimize_3 != 0, threshold, cand);
 	const uint32_t ncand = (uint32_t)cand.size();
-	if(S.n == 0 || ncand == 0){ S.have_db = true; return PCR_OK; }
+	if(S.n == 0 || ncand == 0){ S.have_db = true; S.n_touched = 0; return PCR_OK; }
 	std::vector<uint4> hf(ncand), hr(ncand); std::vector<uint32_t> hfl(ncand);
 	for(uint32_t c = 0;c < ncand;++c){
 		hf[c] = make_uint4(cand[c].fwd.a, cand[c].fwd.c, cand[c].fwd.g, cand[c].fwd.t);
@@ -1458,8 +1498,14 @@ int pcr_select_words(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_
 #undef FIN_ARGS
 		HIP_TRY(hipGetLastError());
 		// the only host synchronisation of the pass: overflow flag + DB size, through the mapped mailbox
-		hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, ctx->stream, d_counters, ctx->mail_dev, ++ctx->mail_seq);
+		++ctx->mail_seq;
+		hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, ctx->stream, d_counters, ctx->mail_dev + (ctx->mail_seq % pcr_ctx::MAIL_RING), ctx->mail_seq);
 		HIP_TRY(hipGetLastError());
+		if(async){
+			S.db_cap = cap; S.n_slots = n_slots;
+			S.n_touched = N_TOUCHED_UNKNOWN; S.n_entries = 1; S.have_db = true;
+			return PCR_OK;
+		}
 		timer.next(3);
 		if((rc = mail_wait(ctx, ctx->mail_seq, h_counters)) != PCR_OK) return rc;
 		timer.next(2);
@@ -1481,9 +1527,67 @@ int pcr_select_words(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_
 	return PCR_OK;
 }
 
+// Look at the counters of the passes pcr_screen_device enqueued.  A pass whose buckets overflowed produced
+// an incomplete DB (and so possibly incomplete amplification bits): grow the buckets and replay it and
+// everything enqueued after it, synchronously, into the same output buffers.
+int drain(pcr_ctx *ctx)
+{
+	if(ctx->pending.empty()) return PCR_OK;
+	std::vector<pcr_ctx::Pending> pend;
+	pend.swap(ctx->pending);
+	int rc;
+	for(size_t i = 0;i < pend.size();++i){
+		uint32_t c[4];
+		if((rc = mail_wait(ctx, pend[i].seq, c)) != PCR_OK) return rc;
+		SeqSet &S = ctx->sets[pend[i].which];
+		if(!(c[0] & 1u)){ S.n_touched = c[3]; S.n_entries = c[3] ? 1 : 0; continue; }
+		uint32_t want = ctx->bucket_cap*2;
+		while(want < c[2] && want < MAX_BUCKET_CAP_GLOBAL) want *= 2;
+		ctx->bucket_cap = std::min(want, MAX_BUCKET_CAP_GLOBAL);
+		for(size_t j = i;j < pend.size();++j){
+			const pcr_ctx::Pending &q = pend[j];
+			if((rc = select_impl(ctx, (pcr_set)q.which, q.pairs.data(), (uint32_t)q.pairs.size(), q.opt5, q.opt3, q.thr, q.min_len, nullptr, false)) != PCR_OK) return rc;
+			if((rc = amplify_launch(ctx, ctx->sets[q.which], q.pairs.data(), (uint32_t)q.pairs.size(), &q.args, q.d_fr, q.d_rf)) != PCR_OK) return rc;
+		}
+		break;
+	}
+	return PCR_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int pcr_select_words(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_pairs, int optimize_5, int optimize_3,
+	float threshold, uint32_t min_oligo_length, uint64_t *n_entries_out)
+{
+	if(!ctx || (n_pairs && !pairs)){ g_err = "pcr_select_words: bad argument"; return PCR_ERR_ARG; }
+	DRAIN(ctx);
+	return select_impl(ctx, which, pairs, n_pairs, optimize_5, optimize_3, threshold, min_oligo_length, n_entries_out, false);
+}
+
+int pcr_screen_device(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_pairs, int optimize_5, int optimize_3,
+	float select_threshold, uint32_t min_oligo_length, const pcr_amplify_args *args, uint64_t *d_bits_fr, uint64_t *d_bits_rf)
+{
+	if(!ctx || !args || (n_pairs && (!pairs || !d_bits_fr || !d_bits_rf))){ g_err = "pcr_screen_device: bad argument"; return PCR_ERR_ARG; }
+	if(ctx->pending.size() + 2 >= pcr_ctx::MAIL_RING) DRAIN(ctx);     // the mailbox ring bounds how far the host may run ahead
+	const uint32_t seq0 = ctx->mail_seq;
+	int rc = select_impl(ctx, which, pairs, n_pairs, optimize_5, optimize_3, select_threshold, min_oligo_length, nullptr, true);
+	if(rc != PCR_OK) return rc;
+	if((rc = amplify_launch(ctx, ctx->sets[which], pairs, n_pairs, args, d_bits_fr, d_bits_rf)) != PCR_OK) return rc;
+	if(ctx->mail_seq != seq0){                                        // a pass was enqueued (not the empty-input shortcut)
+		pcr_ctx::Pending p;
+		p.seq = ctx->mail_seq; p.which = (int)which; p.pairs.assign(pairs, pairs + n_pairs); p.opt5 = optimize_5; p.opt3 = optimize_3;
+		p.thr = select_threshold; p.min_len = min_oligo_length; p.args = *args; p.d_fr = d_bits_fr; p.d_rf = d_bits_rf;
+		ctx->pending.push_back(p);
+	}
+	return PCR_OK;
+}
+
 int64_t pcr_get_entries(pcr_ctx *ctx, pcr_set which, pcr_entry *out, uint64_t cap)
 {
 	if(!ctx){ g_err = "null ctx"; return PCR_ERR_ARG; }
+	DRAIN(ctx);
 	SeqSet &S = ctx->sets[which];
 	if(!S.have_db){ g_err = "pcr_get_entries: no word DB"; return PCR_ERR_STATE; }
 	{ const int rc = count_entries(ctx, S); if(rc != PCR_OK) return rc; }
@@ -1509,6 +1613,7 @@ int pcr_amplify_device(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint3
 	uint64_t *d_bits_fr, uint64_t *d_bits_rf)
 {
 	if(!ctx || !args || (n_pairs && (!pairs || !d_bits_fr || !d_bits_rf))){ g_err = "pcr_amplify_device: bad argument"; return PCR_ERR_ARG; }
+	DRAIN(ctx);
 	HIP_TRY(hipSetDevice(ctx->device));
 	return amplify_launch(ctx, ctx->sets[which], pairs, n_pairs, args, d_bits_fr, d_bits_rf);
 }
@@ -1517,6 +1622,7 @@ int pcr_amplify(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 	uint64_t *bits, uint64_t *bits_fr, uint64_t *bits_rf, float *coverage)
 {
 	if(!ctx || !args || (n_pairs && !pairs)){ g_err = "pcr_amplify: bad argument"; return PCR_ERR_ARG; }
+	DRAIN(ctx);
 	HIP_TRY(hipSetDevice(ctx->device));
 	SeqSet &S = ctx->sets[which];
 	const uint64_t words = (S.n + 63)/64;
@@ -1761,6 +1867,7 @@ int pcr_background_match(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uin
 	uint64_t *bits)
 {
 	if(!ctx || !args || (n_pairs && (!pairs || !bits))){ g_err = "pcr_background_match: bad argument"; return PCR_ERR_ARG; }
+	DRAIN(ctx);
 	HIP_TRY(hipSetDevice(ctx->device));
 	SeqSet &S = ctx->sets[which];
 	if(!S.have_db){ g_err = "pcr_background_match: no word DB (call pcr_select_words first)"; return PCR_ERR_STATE; }
@@ -1785,7 +1892,7 @@ int pcr_background_match(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uin
 	const unsigned threads = 128;
 	const uint32_t n_db = S.n_touched*S.db_cap;
 	const unsigned grid = (n_db + threads - 1)/threads;
-	hipLaunchKernelGGL(k_match, dim3((S.n_touched + MATCH_WAVES - 1)/MATCH_WAVES), dim3(64*MATCH_WAVES), 0, ctx->stream, S.db.p, S.n_touched, S.db_cap,
+	hipLaunchKernelGGL(k_match, dim3((S.n_touched + MATCH_WAVES - 1)/MATCH_WAVES), dim3(64*MATCH_WAVES), 0, ctx->stream, S.db.p, S.n_touched, (const uint32_t *)nullptr, S.db_cap,
 		S.touched.p, S.d_seg_hi, ctx->oligos.p, 2*n_pairs, mask_words, ctx->mask.p, (uint32_t *)nullptr);
 	HIP_TRY(hipGetLastError());
 	uint32_t n_amp = 0, status = 0;
@@ -1827,6 +1934,7 @@ int pcr_multiplex_match(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint
 	int use_taq_mama, uint64_t *bits)
 {
 	if(!ctx || (n_pairs && (!pairs || !bits))){ g_err = "pcr_multiplex_match: bad argument"; return PCR_ERR_ARG; }
+	DRAIN(ctx);
 	HIP_TRY(hipSetDevice(ctx->device));
 	SeqSet &S = ctx->sets[which];
 	const uint64_t words = (S.n + 63)/64;

@@ -161,3 +161,84 @@ def test_bench_shape_sample(both):
         out.append((n, d.entries()))
     assert out[0] == out[1]
     assert out[0][0] > 0
+
+
+# ---------------------------------------------------------------------------- asynchronous fused entry
+def _to_bool(t, n):
+    """[2, P, words] int64 device tensor -> two [P, n] bool arrays."""
+    a = t.cpu().numpy().view(np.uint64)
+    return [np.stack([api.bits_to_bool(a[k, i], n) for i in range(a.shape[1])]) for k in range(2)]
+
+
+def _bits_sync(dev, pairs, thr, thr_t):
+    dev.select_words(pairs, thr, 18)
+    _, fr, rf, _ = dev.amplify(pairs, thr_t, thr_t, 80, 200, False)
+    return np.array(fr), np.array(rf)
+
+
+def test_screen_device_equals_separate_calls(both, oracle):
+    """pcr_screen_device (select + amplify enqueued without a host wait, several passes in flight) leaves the
+    same orientation bitsets as pcr_select_words + pcr_amplify, pass by pass."""
+    import torch
+    rng = random.Random(31)
+    root = rand_seq(rng, 3000)
+    seqs = [root] + [mutate(rng, root, 0.03) for _ in range(40)] + [rand_seq(rng, 2000) for _ in range(5)]
+    batches = []
+    for b in range(5):
+        pairs = []
+        for i in range(10):
+            a = rng.randrange(0, 2600)
+            f = root[a:a + rng.randint(18, 25)]
+            r = revcomp(root[a + 100:a + 100 + rng.randint(18, 25)])
+            pairs.append((oracle.centered_word(f), oracle.centered_word(r)))
+        batches.append(pairs)
+    dev = both[0]
+    dev.load_texts(seqs, [1.0] * len(seqs))
+    thr_t = 1.0
+    thr = float(np.float32(thr_t) * np.float32(0.9))
+    want = [_bits_sync(dev, p, thr, thr_t) for p in batches]
+    assert sum(int(np.count_nonzero(w[0])) + int(np.count_nonzero(w[1])) for w in want) > 0
+    words = int(dev.bitset_words())
+    outs = [torch.full((2, len(p), words), -1, dtype=torch.int64, device="cuda:0") for p in batches]
+    for p, o in zip(batches, outs):
+        dev.screen_device(p, thr, o[0].data_ptr(), o[1].data_ptr(), thr_t, thr_t, 80, 200, False)
+    dev.synchronize()
+    torch.cuda.synchronize()
+    for w, o in zip(want, outs):
+        got = _to_bool(o, len(seqs))
+        assert np.array_equal(got[0], w[0])
+        assert np.array_equal(got[1], w[1])
+
+
+def test_screen_device_replays_after_bucket_overflow(oracle):
+    """A pass whose per-sequence buckets overflow is detected at synchronize() and replayed: same bits as the
+    synchronous path (which retries inside pcr_select_words)."""
+    import torch
+    rng = random.Random(12)
+    seqs = ["A" * 300 + rand_seq(rng, 300) + "AC" * 200 + rand_seq(rng, 100) + "T" * 300, rand_seq(rng, 1200)]
+    s1 = seqs[1]
+    txt = [("A" * 20, "A" * 20), ("AC" * 10, "GT" * 10), (s1[100:120], revcomp(s1[220:240]))]
+    pairs = [(oracle.centered_word(f), oracle.centered_word(r)) for f, r in txt]
+    thr = float(np.float32(1.0) * np.float32(0.9))
+    a = _screener(None)
+    try:
+        a.load_texts(seqs, [1.0, 1.0])
+        want = _bits_sync(a, pairs, thr, 1.0)
+        assert len(a.entries()) > 64                     # more than the initial bucket size in one sequence
+        a.load_texts(seqs, [1.0, 1.0])                   # resets the bucket size
+        words = int(a.bitset_words())
+        o1 = torch.full((2, len(pairs), words), -1, dtype=torch.int64, device="cuda:0")
+        o2 = torch.full((2, len(pairs), words), -1, dtype=torch.int64, device="cuda:0")
+        a.screen_device(pairs, thr, o1[0].data_ptr(), o1[1].data_ptr(), 1.0, 1.0, 80, 200, False)
+        a.screen_device(pairs[2:], thr, o2[0].data_ptr(), o2[1].data_ptr(), 1.0, 1.0, 80, 200, False)
+        a.synchronize()
+        torch.cuda.synchronize()
+        got = _to_bool(o1, len(seqs))
+        assert np.array_equal(got[0], want[0])
+        assert np.array_equal(got[1], want[1])
+        assert want[0].any() or want[1].any()
+        got2 = _to_bool(o2[:, :1], len(seqs))
+        assert np.array_equal(got2[0][0], want[0][2])
+        assert np.array_equal(got2[1][0], want[1][2])
+    finally:
+        a.close()
