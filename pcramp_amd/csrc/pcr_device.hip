@@ -653,9 +653,11 @@ constexpr uint32_t N_TOUCHED_UNKNOWN = 0xFFFFFFFFu;
 
 template<class T> struct DevBuf {
 	T *p = nullptr; size_t cap = 0;
+	uint64_t generation = 0;     // bumped by every (re)allocation: the contents are undefined afterwards
 	int ensure(size_t n)
 	{
 		if(n <= cap) return PCR_OK;
+		++generation;
 		if(p){ (void)hipFree(p); p = nullptr; cap = 0; }
 		const size_t want = std::max<size_t>(n, 16);
 		hipError_t e = hipMalloc((void **)&p, want*sizeof(T));
@@ -723,8 +725,9 @@ struct pcr_ctx {
 	size_t amp_cap = size_t(1) << 20;
 	uint32_t bucket_cap = 64;   // hit slots per sequence (grows on overflow)
 	DevBuf<uint64_t> fin_scratch;   // k_finalize_big's keys
+	std::vector<uint16_t> seed_count; std::vector<uint8_t> seed_fill;   // host scratch of the seed-table builder
 	uint32_t epoch = 0;         // pass counter tagging best[] (see HitSink)
-	uint32_t *best_seen = nullptr;
+	uint64_t best_seen = 0;      // generation of best[] that has been cleared (the allocator may hand the same address back: never compare pointers)
 	// pinned staging for the small per-call host->device payload (candidates, tables, oligos): one async copy
 	// ring of host-mapped staging buffers: a slot is rewritten only after the k_stage that read it has run,
 	// so the host can prepare the next pass while the previous one is still on the GPU
@@ -1309,10 +1312,10 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 	}
 	int rc;
 	if((rc = ctx->best.ensure((size_t)S.n*ncand)) != PCR_OK) return rc;
-	if(ctx->best.p != ctx->best_seen || ctx->epoch >= (1u << 24) - 2){
+	if(ctx->best.generation != ctx->best_seen || ctx->epoch >= (1u << 24) - 2){
 		// fresh (uninitialised) storage or epoch wrap: clear once; afterwards the epoch tag makes clearing unnecessary
 		HIP_TRY(hipMemsetAsync(ctx->best.p, 0, ctx->best.cap*sizeof(uint32_t), ctx->stream));
-		ctx->best_seen = ctx->best.p; ctx->epoch = 0;
+		ctx->best_seen = ctx->best.generation; ctx->epoch = 0;
 	}
 	// ---- scan plan.  version 3 (default): orientations that can be seeded go through the pigeonhole seed
 	// scan; the others, and every tile holding IUPAC target codes, through the bit-sliced counter.
@@ -1328,63 +1331,54 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 		}
 	}
 	else{ for(uint32_t o = 0;o < n_or;++o) or_plain.push_back(o); }
-	// LDS image of the seed scan (layout: pcr_scan_seed.inc).  Too many distinct codes, or a code shared by
-	// more than 255 seeds, sends everything to the bit-sliced path.
-	std::vector<uint32_t> image;
+	// Tables of the seed scan (layout: pcr_scan_seed.inc): presence bitmap + rank (the LDS image), one head
+	// word per distinct code, seed lists of the codes shared by several seeds.  Too many distinct codes, or a
+	// code shared by more than 255 seeds, sends everything to the bit-sliced path.
+	std::vector<uint32_t> image, heads, multi;
 	SeedTables ST; memset(&ST, 0, sizeof(ST));
-	size_t n_seeds = seeds.size();
+	const size_t n_seeds = seeds.size();
 	if(!or_seed.empty()){
-		{   // order by (q, code), generation order within a code: sort packed keys, then permute
-			std::vector<uint64_t> keys(seeds.size());
-			for(size_t i = 0;i < seeds.size();++i) keys[i] = ((uint64_t)seeds[i].q << 56) | ((uint64_t)seeds[i].code << 24) | (uint64_t)i;
-			std::sort(keys.begin(), keys.end());
-			std::vector<pcrhost::Seed> sorted(seeds.size());
-			for(size_t i = 0;i < keys.size();++i) sorted[i] = seeds[keys[i] & 0xFFFFFFu];
-			seeds.swap(sorted);
-		}
-		uint32_t q_mask = 0;
-		for(const pcrhost::Seed &sd : seeds) q_mask |= 1u << (sd.q - 5);
-		uint32_t words = 0;
-		for(int q = 0;q < 4;++q){
-			if(!((q_mask >> q) & 1u)) continue;
-			const uint32_t w = (1u << (2*(q + 5))) >> 5;
-			ST.bm_off[q] = words; words += w;
-			ST.rank_off[q] = words; words += w;
-		}
-		image.assign(words, 0u);
-		std::vector<uint32_t> heads, multi;
+		image.assign(SEED_IMAGE_WORDS, 0u);
+		ctx->seed_count.assign(65536, 0);
+		std::vector<uint16_t> &count = ctx->seed_count;
 		bool overflow = false;
-		for(size_t i = 0;i < seeds.size();){
-			size_t j = i;
-			while(j < seeds.size() && seeds[j].q == seeds[i].q && seeds[j].code == seeds[i].code) ++j;
-			const uint32_t qi = seeds[i].q - 5;
-			if(j - i > 255 || heads.size() >= SEED_MAX_CODES){ overflow = true; break; }
-			image[ST.bm_off[qi] + (seeds[i].code >> 5)] |= 1u << (seeds[i].code & 31);
-			if(j - i == 1) heads.push_back(SEED_SINGLE | ((uint32_t)seeds[i].orient << 8) | seeds[i].off);
-			else{
-				heads.push_back(((uint32_t)multi.size() << 8) | (uint32_t)(j - i));
-				for(size_t k = i;k < j;++k) multi.push_back((uint32_t)seeds[k].orient | ((uint32_t)seeds[k].q << 16) | ((uint32_t)seeds[k].off << 24));
-			}
-			i = j;
+		uint32_t distinct = 0;
+		for(const pcrhost::Seed &sd : seeds){
+			uint16_t &c = count[sd.code];
+			if(c == 0){ image[sd.code >> 5] |= 1u << (sd.code & 31); ++distinct; }
+			if(++c > 255){ overflow = true; break; }
 		}
-		// workgroup LDS budget: 64 KB, of which SeedShared takes ~6 KB
-		const size_t cand_bytes = (ncand <= SEED_CAND_LDS) ? (size_t)ncand*(2*sizeof(uint4) + sizeof(uint32_t)) : 0;
-		if(!overflow && (image.size() + heads.size() + multi.size() + 4)*sizeof(uint32_t) + cand_bytes > 48*1024) overflow = true;
+		if(distinct > SEED_MAX_DISTINCT) overflow = true;
 		if(overflow){
 			or_plain.clear(); or_seed.clear(); image.clear();
 			for(uint32_t o = 0;o < n_or;++o) or_plain.push_back(o);
 		}
 		else{
-			// rank: heads[] is in (q, code) order, so the running bit count is the index
+			uint16_t *rank16 = (uint16_t *)(image.data() + SEED_BITMAP_WORDS);
 			uint32_t run = 0;
-			for(int q = 0;q < 4;++q){
-				if(!((q_mask >> q) & 1u)) continue;
-				const uint32_t w = (1u << (2*(q + 5))) >> 5;
-				for(uint32_t k = 0;k < w;++k){ image[ST.rank_off[q] + k] = run; run += (uint32_t)__builtin_popcount(image[ST.bm_off[q] + k]); }
+			for(uint32_t w = 0;w < SEED_BITMAP_WORDS;++w){ rank16[w] = (uint16_t)run; run += (uint32_t)__builtin_popcount(image[w]); }
+			heads.assign(distinct, 0u);
+			// first pass: reserve the multi ranges (head = start << 8 | filled so far); second: fill
+			uint32_t n_multi = 0;
+			for(const pcrhost::Seed &sd : seeds){
+				const uint32_t h = rank16[sd.code >> 5] + (uint32_t)__builtin_popcount(image[sd.code >> 5] & ((1u << (sd.code & 31)) - 1u));
+				if(count[sd.code] == 1){ heads[h] = SEED_SINGLE | ((uint32_t)sd.orient << 8) | sd.off; continue; }
+				if(heads[h] == 0){ heads[h] = 0x40000000u | n_multi; n_multi += count[sd.code]; }   // bit 30: range reserved, low bits = start
 			}
-			ST.heads_off = (uint32_t)image.size(); image.insert(image.end(), heads.begin(), heads.end());
-			ST.multi_off = (uint32_t)image.size(); image.insert(image.end(), multi.begin(), multi.end());
-			ST.q_mask = q_mask; ST.lds_words = (uint32_t)image.size();
+			multi.assign(n_multi, 0u);
+			std::vector<uint8_t> &fill = ctx->seed_fill; fill.assign(distinct, 0);
+			for(const pcrhost::Seed &sd : seeds){
+				if(count[sd.code] == 1) continue;
+				const uint32_t h = rank16[sd.code >> 5] + (uint32_t)__builtin_popcount(image[sd.code >> 5] & ((1u << (sd.code & 31)) - 1u));
+				const uint32_t start = heads[h] & 0x3FFFFFFFu;
+				multi[start + fill[h]++] = (uint32_t)sd.orient | ((uint32_t)sd.off << 24);
+			}
+			for(uint32_t h = 0;h < distinct;++h){
+				if(heads[h] & SEED_SINGLE) continue;
+				const uint32_t start = heads[h] & 0x3FFFFFFFu;
+				heads[h] = (start << 8) | fill[h];
+			}
+			if(n_multi >= (1u << 22)){ g_err = "pcr_select_words: seed table too large"; return PCR_ERR_CAPACITY; }
 		}
 	}
 	if(getenv("PCRAMP_DEBUG")) fprintf(stderr, "[pcramp] scan plan: %u candidates, %zu seeded orientations (%zu seeds), %zu plain, %u/%u IUPAC tiles\n",
@@ -1400,7 +1394,7 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 		size_t bytes = ncand*(2*sizeof(uint4) + sizeof(uint32_t)) + 1024;
 		bytes += (tab_plain.tab.size() + tab_plain.bias.size() + or_plain.size() + 256)*sizeof(uint32_t);
 		bytes += (tab_seedset.tab.size() + tab_seedset.bias.size() + or_seed.size() + 256)*sizeof(uint32_t);
-		bytes += (image.size() + 64)*sizeof(uint32_t);
+		bytes += (image.size() + heads.size() + multi.size() + 64)*sizeof(uint32_t);
 		timer.next(1);
 		Stager st(ctx);
 		if((rc = st.begin(bytes)) != PCR_OK) return rc;
@@ -1420,7 +1414,11 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 			const std::vector<uint32_t> m = pad256(or_seed);
 			d_map_seedset = st.put(m.data(), m.size());
 		}
-		if(!image.empty()) ST.image = st.put(image.data(), image.size());
+		if(!image.empty()){
+			ST.image = st.put(image.data(), image.size());
+			ST.heads = st.put(heads.data(), heads.size());
+			ST.multi = multi.empty() ? ST.heads : st.put(multi.data(), multi.size());
+		}
 		// the same launch clears the pass's control block (counters | per-sequence fills | segment ends)
 		if((rc = S.ctrl.ensure(8 + 2*(size_t)S.n + 4)) != PCR_OK) return rc;
 		if((rc = st.ship(S.ctrl.p, (8 + 2*(size_t)S.n)*sizeof(uint32_t))) != PCR_OK) return rc;
@@ -1459,7 +1457,7 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 				if(need_plain && (rc = launch_scan2(ctx, S, tab_plain, ncand, sink, d_tab_plain, d_bias_plain, nullptr, S.n_tiles, d_map_plain)) != PCR_OK) return rc;
 				if(!or_seed.empty()){
 					const bool cand_lds = ncand <= SEED_CAND_LDS;
-					const size_t dyn = (size_t)((ST.lds_words + 3u) & ~3u)*sizeof(uint32_t) + (cand_lds ? (size_t)ncand*(2*sizeof(uint4) + sizeof(uint32_t)) : 0);
+					const size_t dyn = cand_lds ? (size_t)ncand*(2*sizeof(uint4) + sizeof(uint32_t)) : 0;
 					const dim3 sgrid((S.n_tiles + SEED_TILES_PER_WG - 1)/SEED_TILES_PER_WG), sblock(SEED_THREADS);
 #define SEED_ARGS S.tb.p, S.planes.p, S.valid.p, S.d_blk_off.p, S.d_nblk_real.p, S.d_len.p, S.d_active.p, S.tile_seq.p, S.tile_pos0.p, \
 	S.tile_degen.p, S.n_tiles, ST, ctx->d_cand_fwd, ctx->d_cand_rc, ctx->d_cand_floor, ncand, sink

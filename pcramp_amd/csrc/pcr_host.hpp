@@ -456,20 +456,59 @@ inline double planes_degeneracy(const Planes &w)
 }
 
 // ---------------------------------------------------------------------------------------------
-// Pigeonhole seeds for the match scan.
+// Seeds for the match scan (generalised pigeonhole).
 //
-// An orientation with m occupied slots and floor f tolerates k = m - f mismatching slots.  Cut
-// the occupied slots into k+1 disjoint blocks: a window reaching the floor matches at least one
-// block in every slot.  So it is enough to examine the windows where some block matches exactly
-// -- found by looking up the TARGET's q-gram (2 bits per base) at the block's offset in a table
-// of seed codes -- and to evaluate only those windows exactly.  An oligo slot with an IUPAC set
-// contributes one seed code per member base (bounded); a target q-gram holding an IUPAC code can
-// match seeds it is not equal to, so tiles containing such bases are scanned by the bit-sliced
-// kernel instead (pcr_device.hip).  Orientations whose blocks would be shorter than MIN_SEED_Q
-// (low thresholds) are "unseedable" and also go to the bit-sliced kernel.
-struct Seed { uint32_t code; uint16_t orient; uint8_t q; uint8_t off; };   // orient = 2*candidate + {0: fwd, 1: rc}; off = slot of the seed's first base
+// An orientation with m occupied slots and floor f tolerates k = m - f mismatching slots.  Cut the
+// occupied slots into disjoint blocks and give block i a budget t_i in {0, 1} with
+// sum(t_i + 1) >= k + 1: if every block had more than t_i mismatches the window would have at least
+// k + 1, so a window reaching the floor has SOME block with at most t_i mismatching slots.  The
+// same holds for any sub-window of a block.  Every block therefore yields a set of 8-gram codes
+// (2 bits per base) at a fixed slot offset:
+//   t = 0, block of q >= 5 slots: the codes whose block positions lie in the oligo's base sets;
+//          when q < 8 the 8-window is padded with don't-care positions (all 4 bases enumerated);
+//   t = 1, 8 slots: those codes plus the ones with exactly one position outside its base set
+//          (25 codes for a plain 8-mer).
+// The scan looks the TARGET's 8-gram up at every position and evaluates exactly only the windows a
+// hit implies.  Among the admissible (number of t=1 blocks, number of t=0 blocks) the cheapest is
+// taken, cost = expected hits per target position = codes / 4^8.  A target 8-gram holding an IUPAC
+// code can match seeds it is not equal to, so tiles containing such bases are scanned by the
+// bit-sliced kernel instead (pcr_device.hip); so are orientations for which no structure exists
+// (low thresholds: blocks shorter than 5) or whose IUPAC slots expand too far.
+struct Seed { uint32_t code; uint16_t orient; uint8_t q; uint8_t off; };   // q = 8 always; orient = 2*candidate + {0: fwd, 1: rc}; off = slot of the 8-window's first base
 
-enum { MIN_SEED_Q = 5, MAX_SEED_Q = 8, MAX_SEED_EXPANSION = 16 };
+enum { SEED_Q = 8, MIN_SEED_BLOCK = 5, MAX_SEED_CODES = 512 /* per orientation */ };
+
+// all codes whose position j lies in sets[j] (4-bit base sets, bit 0 = A ... bit 3 = T; first base in the LOW bits)
+inline void seed_emit(const unsigned sets[SEED_Q], uint32_t orient, uint32_t off, std::vector<Seed> &out)
+{
+	uint32_t fixed = 0; unsigned total = 1;
+	int nf = 0, fpos[SEED_Q]; unsigned nd[SEED_Q]; uint8_t base[SEED_Q][4];
+	for(int j = 0;j < SEED_Q;++j){
+		const unsigned st = sets[j];
+		if(st == 0) return;
+		if((st & (st - 1)) == 0){ fixed |= (uint32_t)__builtin_ctz(st) << (2*j); continue; }
+		unsigned n = 0;
+		for(unsigned b = 0;b < 4;++b){ if(st & (1u << b)) base[nf][n++] = (uint8_t)b; }
+		nd[nf] = n; fpos[nf] = j; ++nf; total *= n;
+	}
+	const size_t at = out.size();
+	out.resize(at + total);
+	Seed *dst = out.data() + at;
+	Seed sd; sd.orient = (uint16_t)orient; sd.q = SEED_Q; sd.off = (uint8_t)off;
+	for(unsigned idx = 0;idx < total;++idx){
+		uint32_t code = fixed; unsigned r = idx;
+		for(int f = 0;f < nf;++f){ code |= (uint32_t)base[f][r % nd[f]] << (2*fpos[f]); r /= nd[f]; }
+		sd.code = code;
+		dst[idx] = sd;
+	}
+}
+
+inline unsigned seed_count(const unsigned sets[SEED_Q])
+{
+	unsigned n = 1;
+	for(int j = 0;j < SEED_Q;++j) n *= (unsigned)__builtin_popcount(sets[j]);
+	return n;
+}
 
 // Appends the seeds of one orientation; returns false (nothing appended) if it cannot be seeded.
 inline bool orientation_seeds(const Planes &m, uint32_t floor_, uint32_t orient, std::vector<Seed> &out)
@@ -478,58 +517,84 @@ inline bool orientation_seeds(const Planes &m, uint32_t floor_, uint32_t orient,
 	const int size = __builtin_popcount(occ);
 	if(size == 0 || floor_ == 0 || floor_ > (uint32_t)size) return floor_ > (uint32_t)size;   // dead orientation: trivially "seeded" with no seeds
 	const int k = size - (int)floor_;
-	const int nblk = k + 1;
-	if(size/nblk < MIN_SEED_Q) return false;
 	const int first = __builtin_ctz(occ);
 	if((occ >> first) != ((size == 32) ? 0xFFFFFFFFu : ((1u << size) - 1u))) return false;   // holes: leave it to the bit-sliced scan
-	// slots holding more than one base, and the 2-bit code planes of the others (A,C,G,T = 0..3)
-	const uint32_t multi = (m.a & m.c) | (m.a & m.g) | (m.a & m.t) | (m.c & m.g) | (m.c & m.t) | (m.g & m.t);
-	const uint32_t lo = m.c | m.t, hi = m.g | m.t;
-	const size_t first_out = out.size();
-	int pos = first;                                          // slot of the block's first base
-	for(int b = 0;b < nblk;++b){
-		const int len = size/nblk + ((b < size % nblk) ? 1 : 0);
-		const int q = std::min<int>(len, MAX_SEED_Q);
-		const uint32_t blk_mask = (len == 32) ? 0xFFFFFFFFu : (((1u << len) - 1u) << pos);
-		if(!(multi & blk_mask)){
-			// plain block: its first q bases, one code
-			uint32_t code = 0;
-			for(int j = 0;j < q;++j) code |= ((((lo >> (pos + j)) & 1u) | (((hi >> (pos + j)) & 1u) << 1)) << (2*j));
-			Seed sd; sd.code = code; sd.orient = (uint16_t)orient; sd.q = (uint8_t)q; sd.off = (uint8_t)pos;
-			out.push_back(sd);
+	unsigned slot_set[32];
+	for(int j = 0;j < first;++j) slot_set[j] = 0;
+	for(int j = first;j < first + size;++j) slot_set[j] = planes_nibble(m, j);
+	for(int j = first + size;j < 32;++j) slot_set[j] = 0;
+	const bool plain = ((m.a & m.c) | (m.a & m.g) | (m.a & m.t) | (m.c & m.g) | (m.c & m.t) | (m.g & m.t)) == 0;   // no IUPAC slot: code counts are known
+
+	// the structures: n1 blocks with budget 1 (8 slots each, at the 3' end of the occupied range) and
+	// n0 = k + 1 - 2*n1 blocks with budget 0 sharing the rest as evenly as possible
+	int best_n1 = -1; double best_cost = 1e30; unsigned best_codes = 0;
+	for(int n1 = 0;2*n1 <= k + 1;++n1){
+		const int n0 = k + 1 - 2*n1;
+		const int rest = size - SEED_Q*n1;
+		if(rest < 0 || (n0 > 0 && rest/n0 < MIN_SEED_BLOCK)) continue;
+		if(n0 == 0 && n1 == 0) continue;
+		unsigned codes = 0; bool ok = true;
+		int pos = first;
+		for(int b = 0;b < n0 && ok;++b){
+			const int len = rest/n0 + ((b < rest % n0) ? 1 : 0);
+			const int q = std::min<int>(len, SEED_Q);
+			const int ws = std::min(pos, 32 - SEED_Q);                    // 8-window holding the block's first q slots
+			unsigned c;
+			if(plain) c = 1u << (2*(SEED_Q - q));
+			else{
+				unsigned sets[SEED_Q];
+				for(int j = 0;j < SEED_Q;++j){ const int sl = ws + j; sets[j] = (sl >= pos && sl < pos + q) ? slot_set[sl] : 15u; }
+				c = seed_count(sets);
+			}
+			if(c > MAX_SEED_CODES) ok = false;
+			codes += c;
 			pos += len;
-			continue;
 		}
-		// IUPAC slots in the block: the q-subwindow with the fewest expansions (first one on ties)
-		unsigned mult[32];
-		for(int j = 0;j < len;++j) mult[j] = (unsigned)__builtin_popcount(planes_nibble(m, pos + j));
-		int best_w = -1; unsigned best_e = ~0u;
-		for(int w = 0;w + q <= len;++w){
-			unsigned e = 1;
-			for(int j = 0;j < q;++j) e *= mult[w + j];
-			if(e < best_e){ best_e = e; best_w = w; }
-		}
-		if(best_e > MAX_SEED_EXPANSION){ out.resize(first_out); return false; }
-		// enumerate the member codes (first base in the LOW bits)
-		unsigned idx[MAX_SEED_Q]; for(int j = 0;j < q;++j) idx[j] = 0;
-		while(true){
-			uint32_t code = 0;
-			for(int j = 0;j < q;++j){
-				const unsigned set = planes_nibble(m, pos + best_w + j);
-				unsigned seen = 0, base = 0;
-				for(unsigned bb = 0;bb < 4;++bb){ if(set & (1u << bb)){ if(seen == idx[j]){ base = bb; break; } ++seen; } }
-				code |= base << (2*j);
+		for(int b = 0;b < n1 && ok;++b){
+			unsigned c;
+			if(plain) c = 1 + 3*SEED_Q;
+			else{
+				unsigned sets[SEED_Q];
+				for(int j = 0;j < SEED_Q;++j) sets[j] = slot_set[pos + j];
+				c = seed_count(sets);
+				const unsigned all = c;
+				for(int j = 0;j < SEED_Q;++j){
+					const unsigned dj = (unsigned)__builtin_popcount(sets[j]);
+					if(dj < 4) c += all/dj*(4 - dj);
+				}
 			}
-			Seed sd; sd.code = code; sd.orient = (uint16_t)orient; sd.q = (uint8_t)q; sd.off = (uint8_t)(pos + best_w);
-			out.push_back(sd);
-			int j = 0;
-			for(;j < q;++j){
-				if(++idx[j] < mult[best_w + j]) break;
-				idx[j] = 0;
-			}
-			if(j == q) break;
+			if(c > MAX_SEED_CODES) ok = false;
+			codes += c;
+			pos += SEED_Q;
 		}
+		if(!ok || codes > MAX_SEED_CODES) continue;
+		const double cost = (double)codes;
+		if(cost < best_cost){ best_cost = cost; best_n1 = n1; best_codes = codes; }
+	}
+	if(best_n1 < 0) return false;
+	(void)best_codes;
+	const int n1 = best_n1, n0 = k + 1 - 2*n1, rest = size - SEED_Q*n1;
+	int pos = first;
+	for(int b = 0;b < n0;++b){
+		const int len = rest/n0 + ((b < rest % n0) ? 1 : 0);
+		const int q = std::min<int>(len, SEED_Q);
+		const int ws = std::min(pos, 32 - SEED_Q);
+		unsigned sets[SEED_Q];
+		for(int j = 0;j < SEED_Q;++j){ const int sl = ws + j; sets[j] = (sl >= pos && sl < pos + q) ? slot_set[sl] : 15u; }
+		seed_emit(sets, orient, (uint32_t)ws, out);
 		pos += len;
+	}
+	for(int b = 0;b < n1;++b){
+		unsigned sets[SEED_Q];
+		for(int j = 0;j < SEED_Q;++j) sets[j] = slot_set[pos + j];
+		seed_emit(sets, orient, (uint32_t)pos, out);                       // no mismatch in the window
+		for(int j = 0;j < SEED_Q;++j){                                      // exactly one, at position j
+			const unsigned keep = sets[j];
+			sets[j] = ~keep & 15u;
+			if(sets[j]) seed_emit(sets, orient, (uint32_t)pos, out);
+			sets[j] = keep;
+		}
+		pos += SEED_Q;
 	}
 	return true;
 }

@@ -184,7 +184,9 @@ def test_seed_filter_is_a_necessary_condition(seed):
 
 def test_seed_filter_declines_low_thresholds():
     word = W.centered_word(W.codes_from_text("ACGTACGTACGTACGTACGT"))
-    assert api.host_orientation_seeds(word, 10) is None        # 11 blocks of <2 bases: not seedable
+    assert api.host_orientation_seeds(word, 10) is None        # k = 10: no block structure fits 20 bases
     assert api.host_orientation_seeds(word, 0) is None         # floor 0: every window matches
-    s = api.host_orientation_seeds(word, 18)                   # k = 2 -> 3 blocks
-    assert s is not None and len(s) == 3 and all(5 <= q <= 8 for _, q, _ in s)
+    s = api.host_orientation_seeds(word, 18)                   # k = 2: three exact blocks (7,7,6 -> 4+4+16 codes) beat 1 + 25
+    assert s is not None and len(s) == 24 and all(q == 8 and off + 8 <= 32 for _, q, off in s)
+    s = api.host_orientation_seeds(word, 20)                   # exact match required: one 8-gram
+    assert s is not None and len(s) == 1
