@@ -723,6 +723,7 @@ struct pcr_ctx {
 	DevBuf<AmpRec> amp_recs; DevBuf<BgPairDev> bg_pairs;
 	DevBuf<thermo::Job> th_jobs; DevBuf<thermo::JobOut> th_out; DevBuf<int> th_dg, th_scratch_i; DevBuf<unsigned short> th_scratch_s;
 	size_t amp_cap = size_t(1) << 20;
+	uint32_t n_cu = 256;        // compute units of the device (hipDeviceProp)
 	uint32_t bucket_cap = 64;   // hit slots per sequence (grows on overflow)
 	DevBuf<uint64_t> fin_scratch;   // k_finalize_big's keys
 	std::vector<uint16_t> seed_count; std::vector<uint8_t> seed_fill;   // host scratch of the seed-table builder
@@ -1063,6 +1064,7 @@ pcr_ctx *pcr_create(int device, void *hip_stream, const pcr_params *params)
 	}
 	if(params){ ctx->params = *params; }
 	else{ ctx->params.pack_max_degen = 256; ctx->params.pack_min_gc = 0.0f; ctx->params.pack_max_gc = 1.0f; }
+	{ hipDeviceProp_t prop; if(hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->n_cu = (uint32_t)prop.multiProcessorCount; }
 	if(const char *v = getenv("PCRAMP_TIMING")) ctx->timing = v[0] == '1';
 	if(const char *v = getenv("PCRAMP_SCAN")){ if(v[0] == '1') ctx->scan_version = 1; else if(v[0] == '2') ctx->scan_version = 2; }   // A/B: 1 = popcount scan, 2 = bit-sliced only
 	ctx->filt.max_degen = ctx->params.pack_max_degen;
@@ -1154,7 +1156,7 @@ int pcr_load_sequences(pcr_ctx *ctx, pcr_set which, const uint8_t *packed4, cons
 		S.blk_off[s] = total_blocks;
 		S.nblk_real[s] = (lengths[s] + 31)/32;
 		total_blocks += S.nblk_real[s] + 2;
-		if(lengths[s] >= 32) n_tiles += (lengths[s] - 31 + TILE_POS - 1)/TILE_POS;
+		if(lengths[s] >= 32) n_tiles += (lengths[s] - 7 + TILE_POS - 1)/TILE_POS;   // tiles cover window starts 0..L-32 AND seed positions 0..L-8 (k_seed)
 	}
 	S.blk_off[n] = total_blocks;
 	S.total_blocks = total_blocks;
@@ -1167,7 +1169,7 @@ int pcr_load_sequences(pcr_ctx *ctx, pcr_set which, const uint8_t *packed4, cons
 	for(uint32_t s = 0;s < n;++s){
 		for(uint64_t b = S.blk_off[s];b < S.blk_off[s + 1];++b) blk_seq[b] = s;
 		if(lengths[s] >= 32){
-			const uint64_t nt = (lengths[s] - 31 + TILE_POS - 1)/TILE_POS;
+			const uint64_t nt = (lengths[s] - 7 + TILE_POS - 1)/TILE_POS;
 			for(uint64_t k = 0;k < nt;++k, ++t){ tile_seq[t] = s; tile_pos0[t] = (uint32_t)(k*TILE_POS); }
 		}
 		pcrhost::PackedSeq q; q.buf = S.packed[s].data(); q.len = lengths[s];
@@ -1458,7 +1460,15 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 				if(!or_seed.empty()){
 					const bool cand_lds = ncand <= SEED_CAND_LDS;
 					const size_t dyn = cand_lds ? (size_t)ncand*(2*sizeof(uint4) + sizeof(uint32_t)) : 0;
-					const dim3 sgrid((S.n_tiles + SEED_TILES_PER_WG - 1)/SEED_TILES_PER_WG), sblock(SEED_THREADS);
+					// persistent workgroups: exactly as many as are resident at once (a partial second round would
+					// run alone at the end), asked of the runtime for this kernel and its dynamic LDS size
+					int per_cu = 0;
+					const hipError_t oe = cand_lds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_seed<true>, SEED_THREADS, dyn)
+						: hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_seed<false>, SEED_THREADS, dyn);
+					per_cu = std::min(per_cu, 6);   // measured at C2 (k_seed us): 3 -> 166, 4 -> 140, 5 -> 121, 6 -> 109, 7 (what the runtime reports) -> 146
+					const uint32_t resident = (oe == hipSuccess && per_cu > 0) ? (uint32_t)per_cu*ctx->n_cu : SEED_MAX_GRID;
+					const dim3 sgrid(std::min<uint32_t>((S.n_tiles + SEED_TILES_PER_GROUP - 1)/SEED_TILES_PER_GROUP, resident)), sblock(SEED_THREADS);
+					if(getenv("PCRAMP_DEBUG")) fprintf(stderr, "[pcramp] k_seed: %d workgroups per CU x %u CUs\n", per_cu, ctx->n_cu);
 #define SEED_ARGS S.tb.p, S.planes.p, S.valid.p, S.d_blk_off.p, S.d_nblk_real.p, S.d_len.p, S.d_active.p, S.tile_seq.p, S.tile_pos0.p, \
 	S.tile_degen.p, S.n_tiles, ST, ctx->d_cand_fwd, ctx->d_cand_rc, ctx->d_cand_floor, ncand, sink
 					if(cand_lds) hipLaunchKernelGGL(k_seed<true>, sgrid, sblock, dyn, ctx->stream, SEED_ARGS);

@@ -69,6 +69,14 @@ def _border_case(rng, oracle):
             f = base[start:start + ln]
             r = revcomp(base[start + 100:start + 100 + rng.randint(18, 25)])
         pairs.append((oracle.centered_word(f), oracle.centered_word(r)))
+    # sites at the 3' end of every sequence: the last regular window (ends 6 bases before the end for a
+    # centred 20-mer) and the very end (irregular words); lengths chosen so that the last window start
+    # falls just before / on / after a tile border
+    for sq in seqs[:-1]:
+        L = len(sq)
+        pairs.append((oracle.centered_word(sq[L - 150:L - 130]), oracle.centered_word(revcomp(sq[L - 26:L - 6]))))
+        pairs.append((oracle.centered_word(sq[L - 26:L - 6]), oracle.centered_word(revcomp(sq[L - 20:]))))
+        pairs.append((oracle.centered_word(sq[L - 140:L - 118]), oracle.centered_word(revcomp(sq[L - 27:L - 5]))))
     # near-copies of the long sequence: sites with 1-3 substitutions
     for _ in range(4):
         seqs.append(mutate(rng, base, 0.03))
