@@ -53,6 +53,9 @@ constexpr int LOC_BIAS = 64;
 
 struct Hit { uint64_t key; uint32_t cand; uint32_t cnt; };
 
+// host-mapped mailbox slot: a pass's counters, then its sequence number (release store)
+struct PassMail { volatile uint32_t counters[4]; volatile uint32_t seq; uint32_t pad[11]; };
+
 struct IrrDev { Planes w; int32_t loc; uint32_t seq; uint32_t meta; /* strand | cws<<8 | ord<<16 */ uint32_t local_id; };
 
 struct DevEntry { Planes w; int32_t loc; uint32_t seq; uint32_t strand; uint32_t pad; };
@@ -288,12 +291,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(
 // outer loop, so their planes and floors are wave-uniform (scalar loads, SGPR operands): 4 and/or +
 // popcount + compare per (word, candidate).  grid.x = ceil(n_live / (IRR_THREADS*IRR_PER_LANE)).
 constexpr int IRR_THREADS = 256, IRR_PER_LANE = 2;
-__global__ __launch_bounds__(IRR_THREADS) void k_scan_irr(const IrrDev *__restrict__ irr, const uint32_t *__restrict__ perm, uint32_t n_live,
+struct IrrArgs { const IrrDev *irr; const uint32_t *perm; uint32_t n_live; };
+
+// the work of irregular-scan workgroup `block` (IRR_THREADS lanes)
+__device__ __forceinline__ void scan_irr_block(uint32_t block, const IrrDev *__restrict__ irr, const uint32_t *__restrict__ perm, uint32_t n_live,
 	const uint8_t *__restrict__ active, const uint4 *__restrict__ cand_fwd, const uint32_t *__restrict__ cand_floor, uint32_t ncand,
-	HitSink sink)
+	const HitSink &sink)
 {
 	uint32_t wa[IRR_PER_LANE], wc[IRR_PER_LANE], wg[IRR_PER_LANE], wt[IRR_PER_LANE];
-	const uint32_t i0 = blockIdx.x*(IRR_THREADS*IRR_PER_LANE) + threadIdx.x;
+	const uint32_t i0 = block*(IRR_THREADS*IRR_PER_LANE) + threadIdx.x;
 #pragma unroll
 	for(int k = 0;k < IRR_PER_LANE;++k){
 		const uint32_t i = i0 + k*IRR_THREADS;
@@ -317,6 +323,13 @@ __global__ __launch_bounds__(IRR_THREADS) void k_scan_irr(const IrrDev *__restri
 			}
 		}
 	}
+}
+
+__global__ __launch_bounds__(IRR_THREADS) void k_scan_irr(const IrrDev *__restrict__ irr, const uint32_t *__restrict__ perm, uint32_t n_live,
+	const uint8_t *__restrict__ active, const uint4 *__restrict__ cand_fwd, const uint32_t *__restrict__ cand_floor, uint32_t ncand,
+	HitSink sink)
+{
+	scan_irr_block(blockIdx.x, irr, perm, n_live, active, cand_fwd, cand_floor, ncand, sink);
 }
 
 #include "pcr_scan_bitsliced.inc"
@@ -514,9 +527,16 @@ __device__ __forceinline__ bool db_slot(uint32_t g, uint32_t n, uint32_t cap, co
 constexpr int MATCH_WAVES = 4;
 __global__ __launch_bounds__(64*MATCH_WAVES) void k_match(const DevEntry *__restrict__ db, uint32_t n_touched, const uint32_t *__restrict__ n_touched_dev, uint32_t cap,
 	const uint32_t *__restrict__ touched, const uint32_t *__restrict__ seg_hi, const OligoDev *__restrict__ oligos, uint32_t n_oligo,
-	uint32_t mask_words, uint32_t *__restrict__ mask, uint32_t *__restrict__ status)
+	uint32_t mask_words, uint32_t *__restrict__ mask, uint32_t *__restrict__ status,
+	const uint32_t *__restrict__ pub_counters, PassMail *pub_mail, uint32_t pub_seq)
 {
 	if(blockIdx.x == 0 && threadIdx.x == 0 && status) status[0] = 0;
+	if(pub_mail && blockIdx.x == 0 && threadIdx.x < 64){        // the pass's counters -> host mailbox (k_publish's job in the fused pass)
+		if(threadIdx.x < 4) pub_mail->counters[threadIdx.x] = pub_counters[threadIdx.x];
+		__threadfence_system();
+		__builtin_amdgcn_wave_barrier();
+		if(threadIdx.x == 0) __hip_atomic_store((uint32_t *)&pub_mail->seq, pub_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+	}
 	if(n_touched_dev) n_touched = *n_touched_dev;                // asynchronous passes: the host does not know it yet
 	const uint32_t lane = threadIdx.x & 63u, sub = lane >> 5, ol = lane & 31u;
 	for(uint32_t t_idx = blockIdx.x*MATCH_WAVES + (threadIdx.x >> 6);t_idx < n_touched;t_idx += gridDim.x*MATCH_WAVES){
@@ -735,7 +755,7 @@ struct pcr_ctx {
 	static constexpr int STAGE_RING = 4;
 	struct StageSlot { uint8_t *host = nullptr, *dev = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool busy = false; };
 	StageSlot stage[STAGE_RING]; int stage_next = 0;
-	struct Mail { volatile uint32_t counters[4]; volatile uint32_t seq; uint32_t pad[11]; };
+	typedef PassMail Mail;
 	static constexpr uint32_t MAIL_RING = 8;
 	Mail *mail = nullptr, *mail_dev = nullptr;   // host-mapped ring (slot = seq % MAIL_RING): k_publish writes it, the host spins on seq
 	uint32_t mail_seq = 0;
@@ -837,13 +857,14 @@ void fill_oligo(OligoDev &o, const uint64_t w[2], float thr2)
 // device arena and clears up to two device regions in the same launch -- a copy-engine transfer and a
 // fill each cost ~4 us plus a ~6 us queue bubble on either side, a kernel runs back to back with the next.
 __global__ void k_stage(const uint4 *__restrict__ src, uint4 *__restrict__ dst, uint32_t n16,
-	uint4 *__restrict__ z0, uint32_t n0, uint4 *__restrict__ z1, uint32_t n1)
+	uint4 *__restrict__ z0, uint32_t n0, uint4 *__restrict__ z1, uint32_t n1, uint4 *__restrict__ z2, uint32_t n2)
 {
 	const uint32_t i = blockIdx.x*blockDim.x + threadIdx.x, stride = gridDim.x*blockDim.x;
 	for(uint32_t k = i;k < n16;k += stride) dst[k] = src[k];
 	const uint4 zero = make_uint4(0, 0, 0, 0);
 	for(uint32_t k = i;k < n0;k += stride) z0[k] = zero;
 	for(uint32_t k = i;k < n1;k += stride) z1[k] = zero;
+	for(uint32_t k = i;k < n2;k += stride) z2[k] = zero;
 }
 
 struct Stager {
@@ -878,14 +899,14 @@ struct Stager {
 	}
 	// z0/z1: device regions to clear in the same launch (16-byte aligned, sizes rounded UP to 16 bytes: the
 	// caller's buffers must be allocated with that slack)
-	int ship(void *z0 = nullptr, size_t bytes0 = 0, void *z1 = nullptr, size_t bytes1 = 0)
+	int ship(void *z0 = nullptr, size_t bytes0 = 0, void *z1 = nullptr, size_t bytes1 = 0, void *z2 = nullptr, size_t bytes2 = 0)
 	{
-		const uint32_t n16 = (uint32_t)((used + 15)/16), n0 = (uint32_t)((bytes0 + 15)/16), n1 = (uint32_t)((bytes1 + 15)/16);
-		const uint32_t most = std::max(n16, std::max(n0, n1));
+		const uint32_t n16 = (uint32_t)((used + 15)/16), n0 = (uint32_t)((bytes0 + 15)/16), n1 = (uint32_t)((bytes1 + 15)/16), n2 = (uint32_t)((bytes2 + 15)/16);
+		const uint32_t most = std::max(std::max(n16, n2), std::max(n0, n1));
 		if(most){
 			const unsigned grid = std::min<unsigned>((most + 255)/256, 512u);
 			hipLaunchKernelGGL(k_stage, dim3(grid), dim3(256), 0, ctx->stream, (const uint4 *)slot->dev, (uint4 *)ctx->arena.p, n16,
-				(uint4 *)z0, n0, (uint4 *)z1, n1);
+				(uint4 *)z0, n0, (uint4 *)z1, n1, (uint4 *)z2, n2);
 			HIP_TRY(hipGetLastError());
 		}
 		HIP_TRY(hipEventRecord(slot->done, ctx->stream));
@@ -922,8 +943,25 @@ int mail_wait(pcr_ctx *ctx, uint32_t seq, uint32_t out[4])
 	return PCR_OK;
 }
 
+// pcr_screen_device: the amplicon screen's oligo table and the clearing of its result bitsets ride in the
+// select pass's staging launch, and the pass's counters are published by k_match instead of k_publish.
+struct FusedAmp {
+	const pcr_pair *pairs; uint32_t n_pairs; const pcr_amplify_args *a; uint64_t *d_fr, *d_rf;
+	bool staged = false; const OligoDev *d_oligos = nullptr; uint32_t pub_seq = 0; const uint32_t *pub_counters = nullptr;
+};
+
+void build_oligos(const pcr_pair *pairs, uint32_t n_pairs, const pcr_amplify_args *a, std::vector<OligoDev> &ol)
+{
+	const float thr2 = a->collect_threshold*a->collect_threshold;                // pcr_assay.cpp:31-32
+	ol.resize(2*(size_t)n_pairs);
+	for(uint32_t i = 0;i < n_pairs;++i){
+		fill_oligo(ol[2*i], pairs[i].f.w, thr2);
+		fill_oligo(ol[2*i + 1], pairs[i].r.w, thr2);
+	}
+}
+
 int amplify_launch(pcr_ctx *ctx, SeqSet &S, const pcr_pair *pairs, uint32_t n_pairs, const pcr_amplify_args *a,
-	uint64_t *d_fr, uint64_t *d_rf)
+	uint64_t *d_fr, uint64_t *d_rf, const FusedAmp *fa = nullptr)
 {
 	if(!S.have_db){ g_err = "pcr_amplify: no word DB (call pcr_select_words first)"; return PCR_ERR_STATE; }
 	const uint64_t words = (S.n + 63)/64;
@@ -936,23 +974,23 @@ int amplify_launch(pcr_ctx *ctx, SeqSet &S, const pcr_pair *pairs, uint32_t n_pa
 		return PCR_OK;
 	}
 	HostTimer timer(ctx, 4);
-	const float thr2 = a->collect_threshold*a->collect_threshold;                // pcr_assay.cpp:31-32
-	std::vector<OligoDev> ol(2*(size_t)n_pairs);
-	for(uint32_t i = 0;i < n_pairs;++i){
-		fill_oligo(ol[2*i], pairs[i].f.w, thr2);
-		fill_oligo(ol[2*i + 1], pairs[i].r.w, thr2);
-	}
 	int rc;
-	Stager st(ctx);
-	if((rc = st.begin(ol.size()*sizeof(OligoDev) + 64)) != PCR_OK) return rc;
-	ctx->d_oligos = st.put(ol.data(), ol.size());
-	// the result bitsets are cleared by the staging kernel when they allow 16-byte stores
-	const bool vec_ok = ((uintptr_t)d_fr % 16 == 0) && ((uintptr_t)d_rf % 16 == 0) && (bits_bytes % 16 == 0);
-	if(!vec_ok){
-		HIP_TRY(hipMemsetAsync(d_fr, 0, bits_bytes, ctx->stream));
-		HIP_TRY(hipMemsetAsync(d_rf, 0, bits_bytes, ctx->stream));
+	const bool prestaged = fa && fa->staged;
+	if(prestaged) ctx->d_oligos = fa->d_oligos;
+	else{
+		std::vector<OligoDev> ol;
+		build_oligos(pairs, n_pairs, a, ol);
+		Stager st(ctx);
+		if((rc = st.begin(ol.size()*sizeof(OligoDev) + 64)) != PCR_OK) return rc;
+		ctx->d_oligos = st.put(ol.data(), ol.size());
+		// the result bitsets are cleared by the staging kernel when they allow 16-byte stores
+		const bool vec_ok = ((uintptr_t)d_fr % 16 == 0) && ((uintptr_t)d_rf % 16 == 0) && (bits_bytes % 16 == 0);
+		if(!vec_ok){
+			HIP_TRY(hipMemsetAsync(d_fr, 0, bits_bytes, ctx->stream));
+			HIP_TRY(hipMemsetAsync(d_rf, 0, bits_bytes, ctx->stream));
+		}
+		if((rc = vec_ok ? st.ship(d_fr, bits_bytes, d_rf, bits_bytes) : st.ship()) != PCR_OK) return rc;
 	}
-	if((rc = vec_ok ? st.ship(d_fr, bits_bytes, d_rf, bits_bytes) : st.ship()) != PCR_OK) return rc;
 	timer.next(5);
 	const uint32_t mask_words = (2*n_pairs + 31)/32;
 	if((rc = ctx->mask.ensure((size_t)S.n_slots*mask_words)) != PCR_OK) return rc;
@@ -966,8 +1004,10 @@ int amplify_launch(pcr_ctx *ctx, SeqSet &S, const pcr_pair *pairs, uint32_t n_pa
 	const unsigned grid = dev_n ? (unsigned)std::min<uint64_t>(((uint64_t)S.n*S.db_cap + threads - 1)/threads, 1024) : (n_db + threads - 1)/threads;
 	const unsigned mgrid = dev_n ? std::min<unsigned>((S.n + MATCH_WAVES - 1)/MATCH_WAVES, 1024u) : (n_t + MATCH_WAVES - 1)/MATCH_WAVES;
 	// k_match also clears the status word (it runs before k_pair in stream order)
-	hipLaunchKernelGGL(k_match, dim3(mgrid), dim3(64*MATCH_WAVES), 0, ctx->stream, S.db.p, n_t, n_dev, S.db_cap,
-		S.touched.p, S.d_seg_hi, ctx->d_oligos, 2*n_pairs, mask_words, ctx->mask.p, ctx->status.p);
+	hipLaunchKernelGGL(k_match, dim3(std::max(mgrid, 1u)), dim3(64*MATCH_WAVES), 0, ctx->stream, S.db.p, n_t, n_dev, S.db_cap,
+		S.touched.p, S.d_seg_hi, ctx->d_oligos, 2*n_pairs, mask_words, ctx->mask.p, ctx->status.p,
+		prestaged ? fa->pub_counters : (const uint32_t *)nullptr, prestaged ? ctx->mail_dev + (fa->pub_seq % pcr_ctx::MAIL_RING) : (pcr_ctx::Mail *)nullptr,
+		prestaged ? fa->pub_seq : 0u);
 	HIP_TRY(hipGetLastError());
 	hipLaunchKernelGGL(k_pair, dim3(grid), dim3(threads), 0, ctx->stream, S.db.p, n_db, n_dev, S.db_cap, S.touched.p, S.d_seg_hi, ctx->mask.p,
 		mask_words, ctx->d_oligos, n_pairs, S.planes.p, S.d_blk_off.p, S.d_len.p, S.d_active.p, a->amp_min, a->amp_max,
@@ -1292,7 +1332,7 @@ namespace {
 // pcr_select_words proper.  async: enqueue one attempt and return without looking at the counters
 // (pcr_screen_device; the caller records the pass as pending).
 int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_pairs, int optimize_5, int optimize_3,
-	float threshold, uint32_t min_oligo_length, uint64_t *n_entries_out, bool async)
+	float threshold, uint32_t min_oligo_length, uint64_t *n_entries_out, bool async, FusedAmp *fa = nullptr)
 {
 	if(!ctx || (n_pairs && !pairs)){ g_err = "pcr_select_words: bad argument"; return PCR_ERR_ARG; }
 	if(min_oligo_length < 1 || min_oligo_length > 32){ g_err = "pcr_select_words: min_oligo_length must be in [1,32]"; return PCR_ERR_ARG; }
@@ -1397,6 +1437,16 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 		bytes += (tab_plain.tab.size() + tab_plain.bias.size() + or_plain.size() + 256)*sizeof(uint32_t);
 		bytes += (tab_seedset.tab.size() + tab_seedset.bias.size() + or_seed.size() + 256)*sizeof(uint32_t);
 		bytes += (image.size() + heads.size() + multi.size() + 64)*sizeof(uint32_t);
+		// fused pass: the amplicon screen's oligo table travels with the scan tables, its result bitsets are
+		// cleared by the same launch
+		std::vector<OligoDev> ol;
+		size_t bits_bytes = 0;
+		bool fuse = false;
+		if(fa && fa->n_pairs){
+			bits_bytes = (size_t)fa->n_pairs*((S.n + 63)/64)*sizeof(uint64_t);
+			fuse = ((uintptr_t)fa->d_fr % 16 == 0) && ((uintptr_t)fa->d_rf % 16 == 0) && (bits_bytes % 16 == 0);
+			if(fuse){ build_oligos(fa->pairs, fa->n_pairs, fa->a, ol); bytes += ol.size()*sizeof(OligoDev) + 64; }
+		}
 		timer.next(1);
 		Stager st(ctx);
 		if((rc = st.begin(bytes)) != PCR_OK) return rc;
@@ -1423,7 +1473,12 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 		}
 		// the same launch clears the pass's control block (counters | per-sequence fills | segment ends)
 		if((rc = S.ctrl.ensure(8 + 2*(size_t)S.n + 4)) != PCR_OK) return rc;
-		if((rc = st.ship(S.ctrl.p, (8 + 2*(size_t)S.n)*sizeof(uint32_t))) != PCR_OK) return rc;
+		if(fuse){
+			fa->d_oligos = st.put(ol.data(), ol.size());
+			fa->staged = true;
+			if((rc = st.ship(S.ctrl.p, (8 + 2*(size_t)S.n)*sizeof(uint32_t), fa->d_fr, bits_bytes, fa->d_rf, bits_bytes)) != PCR_OK) return rc;
+		}
+		else if((rc = st.ship(S.ctrl.p, (8 + 2*(size_t)S.n)*sizeof(uint32_t))) != PCR_OK) return rc;
 	}
 
 	timer.next(2);
@@ -1443,6 +1498,9 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 		++ctx->epoch;
 		HitSink sink; sink.best = ctx->best.p; sink.hits = ctx->hits.p; sink.seq_count = d_seq_count;
 		sink.counters = d_counters; sink.cap = cap; sink.ncand = ncand; sink.epoch = ctx->epoch;
+		uint32_t n_live = 0;                              // irregular words whose size counter reaches min_oligo_length
+		for(uint32_t k = std::min<uint32_t>(min_oligo_length, 256);k < 256;++k) n_live += S.irr_size_count[k];
+		bool irr_fused = false;                           // scanned by extra workgroups of k_seed
 		if(S.n_tiles){
 			hipEvent_t e0 = nullptr, e1 = nullptr;
 			if(ctx->prof){
@@ -1465,14 +1523,26 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 					int per_cu = 0;
 					const hipError_t oe = cand_lds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_seed<true>, SEED_THREADS, dyn)
 						: hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_seed<false>, SEED_THREADS, dyn);
-					per_cu = std::min(per_cu, 6);   // measured at C2 (k_seed us): 3 -> 166, 4 -> 140, 5 -> 121, 6 -> 109, 7 (what the runtime reports) -> 146
+					// The runtime's answer was one too high twice (7 for 21.6 KB of LDS, 6 for 27.2 KB: the extra workgroup
+					// ran as a second round, 146 vs 109 us at C2); both cases fit "160 KB, allocated in 4 KB units".
+					{
+						const size_t lds_wg = ((sizeof(SeedShared) + dyn + 4095)/4096)*4096;
+						per_cu = std::min<int>(per_cu, (int)((160*1024)/lds_wg));
+						if(per_cu < 1) per_cu = 1;
+					}
 					const uint32_t resident = (oe == hipSuccess && per_cu > 0) ? (uint32_t)per_cu*ctx->n_cu : SEED_MAX_GRID;
 					const dim3 sgrid(std::min<uint32_t>((S.n_tiles + SEED_TILES_PER_GROUP - 1)/SEED_TILES_PER_GROUP, resident)), sblock(SEED_THREADS);
+					// the irregular words ride along as extra workgroups behind the persistent ones: they fill the
+					// issue slots the latency-bound seed scan leaves idle instead of running alone afterwards
+					IrrArgs IA; IA.irr = S.irr.p; IA.perm = S.irr_perm.p; IA.n_live = n_live;
+					const uint32_t irr_wgs = (n_live + IRR_THREADS*IRR_PER_LANE - 1)/(IRR_THREADS*IRR_PER_LANE);
+					const dim3 fgrid(sgrid.x + irr_wgs);
+					irr_fused = true;
 					if(getenv("PCRAMP_DEBUG")) fprintf(stderr, "[pcramp] k_seed: %d workgroups per CU x %u CUs\n", per_cu, ctx->n_cu);
 #define SEED_ARGS S.tb.p, S.planes.p, S.valid.p, S.d_blk_off.p, S.d_nblk_real.p, S.d_len.p, S.d_active.p, S.tile_seq.p, S.tile_pos0.p, \
-	S.tile_degen.p, S.n_tiles, ST, ctx->d_cand_fwd, ctx->d_cand_rc, ctx->d_cand_floor, ncand, sink
-					if(cand_lds) hipLaunchKernelGGL(k_seed<true>, sgrid, sblock, dyn, ctx->stream, SEED_ARGS);
-					else hipLaunchKernelGGL(k_seed<false>, sgrid, sblock, dyn, ctx->stream, SEED_ARGS);
+	S.tile_degen.p, S.n_tiles, ST, ctx->d_cand_fwd, ctx->d_cand_rc, ctx->d_cand_floor, ncand, IA, sgrid.x, sink
+					if(cand_lds) hipLaunchKernelGGL(k_seed<true>, fgrid, sblock, dyn, ctx->stream, SEED_ARGS);
+					else hipLaunchKernelGGL(k_seed<false>, fgrid, sblock, dyn, ctx->stream, SEED_ARGS);
 #undef SEED_ARGS
 					HIP_TRY(hipGetLastError());
 					if(need_seedset && (rc = launch_scan2(ctx, S, tab_seedset, ncand, sink, d_tab_seedset, d_bias_seedset, S.degen_tiles.p,
@@ -1484,9 +1554,7 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 				ctx->prof_events.push_back(std::make_pair(e0, e1));
 			}
 		}
-		uint32_t n_live = 0;
-		for(uint32_t k = std::min<uint32_t>(min_oligo_length, 256);k < 256;++k) n_live += S.irr_size_count[k];
-		if(n_live){
+		if(n_live && !irr_fused){
 			const unsigned irr_grid = (n_live + IRR_THREADS*IRR_PER_LANE - 1)/(IRR_THREADS*IRR_PER_LANE);
 			hipLaunchKernelGGL(k_scan_irr, dim3(irr_grid), dim3(IRR_THREADS), 0, ctx->stream, S.irr.p, S.irr_perm.p, n_live,
 				S.d_active.p, ctx->d_cand_fwd, ctx->d_cand_floor, ncand, sink);
@@ -1507,8 +1575,11 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 		HIP_TRY(hipGetLastError());
 		// the only host synchronisation of the pass: overflow flag + DB size, through the mapped mailbox
 		++ctx->mail_seq;
-		hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, ctx->stream, d_counters, ctx->mail_dev + (ctx->mail_seq % pcr_ctx::MAIL_RING), ctx->mail_seq);
-		HIP_TRY(hipGetLastError());
+		if(async && fa && fa->staged){ fa->pub_seq = ctx->mail_seq; fa->pub_counters = d_counters; }   // k_match publishes
+		else{
+			hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, ctx->stream, d_counters, ctx->mail_dev + (ctx->mail_seq % pcr_ctx::MAIL_RING), ctx->mail_seq);
+			HIP_TRY(hipGetLastError());
+		}
 		if(async){
 			S.db_cap = cap; S.n_slots = n_slots;
 			S.n_touched = N_TOUCHED_UNKNOWN; S.n_entries = 1; S.have_db = true;
@@ -1580,9 +1651,10 @@ int pcr_screen_device(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32
 	if(!ctx || !args || (n_pairs && (!pairs || !d_bits_fr || !d_bits_rf))){ g_err = "pcr_screen_device: bad argument"; return PCR_ERR_ARG; }
 	if(ctx->pending.size() + 2 >= pcr_ctx::MAIL_RING) DRAIN(ctx);     // the mailbox ring bounds how far the host may run ahead
 	const uint32_t seq0 = ctx->mail_seq;
-	int rc = select_impl(ctx, which, pairs, n_pairs, optimize_5, optimize_3, select_threshold, min_oligo_length, nullptr, true);
+	FusedAmp fa; fa.pairs = pairs; fa.n_pairs = n_pairs; fa.a = args; fa.d_fr = d_bits_fr; fa.d_rf = d_bits_rf;
+	int rc = select_impl(ctx, which, pairs, n_pairs, optimize_5, optimize_3, select_threshold, min_oligo_length, nullptr, true, &fa);
 	if(rc != PCR_OK) return rc;
-	if((rc = amplify_launch(ctx, ctx->sets[which], pairs, n_pairs, args, d_bits_fr, d_bits_rf)) != PCR_OK) return rc;
+	if((rc = amplify_launch(ctx, ctx->sets[which], pairs, n_pairs, args, d_bits_fr, d_bits_rf, &fa)) != PCR_OK) return rc;
 	if(ctx->mail_seq != seq0){                                        // a pass was enqueued (not the empty-input shortcut)
 		pcr_ctx::Pending p;
 		p.seq = ctx->mail_seq; p.which = (int)which; p.pairs.assign(pairs, pairs + n_pairs); p.opt5 = optimize_5; p.opt3 = optimize_3;
@@ -1901,7 +1973,7 @@ int pcr_background_match(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uin
 	const uint32_t n_db = S.n_touched*S.db_cap;
 	const unsigned grid = (n_db + threads - 1)/threads;
 	hipLaunchKernelGGL(k_match, dim3((S.n_touched + MATCH_WAVES - 1)/MATCH_WAVES), dim3(64*MATCH_WAVES), 0, ctx->stream, S.db.p, S.n_touched, (const uint32_t *)nullptr, S.db_cap,
-		S.touched.p, S.d_seg_hi, ctx->oligos.p, 2*n_pairs, mask_words, ctx->mask.p, (uint32_t *)nullptr);
+		S.touched.p, S.d_seg_hi, ctx->oligos.p, 2*n_pairs, mask_words, ctx->mask.p, (uint32_t *)nullptr, (const uint32_t *)nullptr, (pcr_ctx::Mail *)nullptr, 0u);
 	HIP_TRY(hipGetLastError());
 	uint32_t n_amp = 0, status = 0;
 	for(int attempt = 0;;++attempt){
