@@ -332,6 +332,9 @@ __global__ __launch_bounds__(IRR_THREADS) void k_scan_irr(const IrrDev *__restri
 	scan_irr_block(blockIdx.x, irr, perm, n_live, active, cand_fwd, cand_floor, ncand, sink);
 }
 
+// LDS hand-off between lanes of ONE wave: order the wave's own LDS traffic, no workgroup barrier
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
 #include "pcr_scan_bitsliced.inc"
 #include "pcr_scan_seed.inc"
 
@@ -342,8 +345,6 @@ __global__ __launch_bounds__(IRR_THREADS) void k_scan_irr(const IrrDev *__restri
 constexpr int FIN_WAVES = 8;          // one wave per sequence, 8 sequences per workgroup (1 when the buckets outgrow 1024 hits: LDS)
 constexpr uint32_t MAX_BUCKET_CAP = 8192;   // 8192 keys x 8 B = the 64 KB of LDS one wave may sort in
 
-// LDS hand-off between lanes of ONE wave: order the wave's own LDS traffic, no workgroup barrier
-__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 
 __device__ void materialise_entry(uint64_t k, const uint4 *__restrict__ planes, const uint64_t *__restrict__ blk_off,
 	const IrrDev *__restrict__ irr, const uint32_t *__restrict__ irr_off, DevEntry &e)
@@ -383,10 +384,11 @@ __global__ __launch_bounds__(64*WAVES) void k_finalize(const Hit *__restrict__ h
 	extern __shared__ __attribute__((aligned(16))) uint64_t fin_lds[];   // WAVES x np2cap keys
 	__shared__ uint32_t part_all[64*WAVES];
 	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	const uint32_t t_idx = blockIdx.x*WAVES + wave;
-	if(t_idx >= counters[3]) return;            // only sequences that received hits (seg_hi of the others stays 0 = empty)
-	const uint32_t seq = touched[t_idx];
 	uint32_t np2cap = 1; while(np2cap < cap) np2cap <<= 1;
+	// only sequences that received hits (seg_hi of the others stays 0 = empty).  One workgroup per 8 sequences of
+	// the whole set; 256 fat workgroups walking the list were slower (10.7 vs 7.4 us at C2: latency-, not dispatch-bound)
+	for(uint32_t t_idx = blockIdx.x*WAVES + wave;t_idx < counters[3];t_idx += gridDim.x*WAVES){
+	const uint32_t seq = touched[t_idx];
 	uint64_t *fin_keys = fin_lds + (size_t)wave*np2cap;
 	uint32_t *part = part_all + wave*64;
 	const uint32_t n = min(seq_count[seq], cap);
@@ -438,6 +440,8 @@ __global__ __launch_bounds__(64*WAVES) void k_finalize(const Hit *__restrict__ h
 			db[(size_t)seq*cap + rank] = e;
 			++rank;
 		}
+	}
+	wave_sync();                                 // the wave's LDS keys are reused by its next sequence
 	}
 }
 
@@ -1531,7 +1535,8 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 						if(per_cu < 1) per_cu = 1;
 					}
 					const uint32_t resident = (oe == hipSuccess && per_cu > 0) ? (uint32_t)per_cu*ctx->n_cu : SEED_MAX_GRID;
-					const dim3 sgrid(std::min<uint32_t>((S.n_tiles + SEED_TILES_PER_GROUP - 1)/SEED_TILES_PER_GROUP, resident)), sblock(SEED_THREADS);
+					const uint32_t tiles_per_wg = SEED_WAVES*SEED_TILES_PER_WAVE;
+					const dim3 sgrid(std::min<uint32_t>((S.n_tiles + tiles_per_wg - 1)/tiles_per_wg, resident)), sblock(SEED_THREADS);
 					// the irregular words ride along as extra workgroups behind the persistent ones: they fill the
 					// issue slots the latency-bound seed scan leaves idle instead of running alone afterwards
 					IrrArgs IA; IA.irr = S.irr.p; IA.perm = S.irr_perm.p; IA.n_live = n_live;
