@@ -1244,7 +1244,11 @@ int pcr_load_sequences(pcr_ctx *ctx, pcr_set which, const uint8_t *packed4, cons
 	if((rc = S.seg_hi.ensure(n)) != PCR_OK) return fail(rc);
 #define H2D(dst, src, bytes) do{ if((bytes) > 0){ hipError_t e_ = hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice); \
 	if(e_ != hipSuccess){ g_err = std::string("hipMemcpy: ") + hipGetErrorString(e_); return fail(PCR_ERR_DEVICE); } } }while(0)
-	for(uint32_t s = 0;s < n;++s) H2D(d_packed.p + dev_byte_off[s], S.packed[s].data(), S.packed[s].size());
+	{   // one transfer for all sequences (a copy per sequence was 10 000 copy-engine packets at C2)
+		std::vector<uint8_t> flat(total_bytes);
+		for(uint32_t s = 0;s < n;++s){ if(!S.packed[s].empty()) memcpy(flat.data() + dev_byte_off[s], S.packed[s].data(), S.packed[s].size()); }
+		H2D(d_packed.p, flat.data(), flat.size());
+	}
 	H2D(d_byte_off.p, dev_byte_off.data(), n*sizeof(uint64_t));
 	H2D(S.blk_seq.p, blk_seq.data(), total_blocks*sizeof(uint32_t));
 	H2D(S.tile_seq.p, tile_seq.data(), n_tiles*sizeof(uint32_t));
