@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--random-primers", action="store_true", help="diagnostic: primers unrelated to the targets (no hits)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--gather-every", type=int, default=8,
+                    help="N>1: passes per all-gather (their bitsets travel in one collective)")
     ap.add_argument("--separate-calls", action="store_true",
                     help="pcr_select_words + pcr_amplify_device per step (host wait between them) instead of pcr_screen_device")
     ap.add_argument("--target-threshold", type=float, default=1.0,
@@ -92,8 +94,10 @@ def main():
     # PCRAMP_BENCH_REHEARSAL=1: exercise the N>1 code path on a box with fewer GPUs than ranks -- gloo
     # collectives on host copies, ranks share the visible GPUs.  The number it prints is not a measurement.
     rehearsal = os.environ.get("PCRAMP_BENCH_REHEARSAL") == "1"
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("PCRAMP_BENCH_FORCE_DIST") == "1"   # FORCE_DIST: run the collective path with one rank
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("gloo" if rehearsal else "nccl", rank=rank, world_size=world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
@@ -126,14 +130,34 @@ def main():
     scr = api.Screener(local_rank, stream=stream)
     scr.load_sequences(wl["packed"], wl["byte_offsets"], wl["lengths"])
     words = int(scr.bitset_words())
-    local = torch.zeros((2, P, words), dtype=torch.int64, device=dev_t)
-    gathered = torch.zeros((world, 2, P, words), dtype=torch.int64, device="cpu" if rehearsal else dev_t) if world > 1 else None
+    # The exchange is batched and pipelined: K passes write their bitsets into the K slices of one buffer, one
+    # all-gather ships the batch (fewer, larger collectives: a torch collective costs the host ~100 us, a pass
+    # 150 us of GPU time), and it runs on RCCL's stream while the next batch computes into the other buffer.
+    NBUF = 2
+    K = max(1, args.gather_every) if use_dist else 1
+    local = [torch.zeros((K, 2, P, words), dtype=torch.int64, device=dev_t) for _ in range(NBUF)]
+    gathered = [torch.zeros((world, K, 2, P, words), dtype=torch.int64, device="cpu" if rehearsal else dev_t) for _ in range(NBUF)] if use_dist else None
+    works = [None] * NBUF
+    step_no = [0]
 
     host_t = [0.0, 0.0]          # PCRAMP_TIMING=1: wall time inside the two ABI calls (diagnostic)
     timing = os.environ.get("PCRAMP_TIMING") == "1"
-    p_fr, p_rf = local[0].data_ptr(), local[1].data_ptr()
+    ptrs = [[(t[k, 0].data_ptr(), t[k, 1].data_ptr()) for k in range(K)] for t in local]
+
+    def ship(b):
+        if rehearsal:
+            dist.all_gather_into_tensor(gathered[b].view(-1), local[b].cpu().view(-1))
+        else:
+            works[b] = dist.all_gather_into_tensor(gathered[b].view(-1), local[b].view(-1), async_op=True)
 
     def step():
+        k = step_no[0] % K
+        b = (step_no[0] // K) % NBUF
+        step_no[0] += 1
+        if k == 0 and works[b] is not None:
+            works[b].wait()          # the gather that still reads this buffer (two batches ago) is ordered before the new pass
+            works[b] = None
+        p_fr, p_rf = ptrs[b][k]
         if timing:
             t_a = time.perf_counter()
         if args.separate_calls:
@@ -149,26 +173,37 @@ def main():
             t_c = time.perf_counter()
             host_t[0] += t_b - t_a
             host_t[1] += t_c - t_b
-        if world > 1:
-            # the path's only exchange: every rank's [2, P, words] orientation bitsets (31 KB at C2), stream-ordered
-            # behind the screen on the same stream
-            dist.all_gather_into_tensor(gathered.view(-1), (local.cpu() if rehearsal else local).view(-1))
+        if use_dist and k == K - 1:
+            # the path's only exchange: every rank's [K, 2, P, words] orientation bitsets (31 KB per pass at C2),
+            # ordered behind the screens by torch (the collective waits for the current stream)
+            ship(b)
+
+    def drain_works():
+        if use_dist and step_no[0] % K != 0:      # a partial batch is still unsent
+            ship((step_no[0] // K) % NBUF)
+            step_no[0] += K - step_no[0] % K
+        for i in range(NBUF):
+            if works[i] is not None:
+                works[i].wait()
+                works[i] = None
 
     for _ in range(args.warmup):
         step()
     scr.synchronize()
+    drain_works()
     torch.cuda.synchronize()
     scr.profile(True)
     scr.profile_read(reset=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     scr.synchronize()          # inspects the counters of the passes still in flight (replays on bucket overflow)
+    drain_works()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -179,12 +214,13 @@ def main():
         sys.stderr.write("[bench] host us/step inside select_words %.1f, amplify_device %.1f; step %.1f\n"
                          % (host_t[0] / n_st * 1e6, host_t[1] / n_st * 1e6, dt / args.steps * 1e6))
 
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev_t)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    n_set = int(sum(bin(int(x) & 0xFFFFFFFFFFFFFFFF).count("1") for x in (local[0] | local[1]).flatten().tolist()))
+    last = local[0][0]               # the first pass of the first batch buffer (every pass screens the same pairs)
+    n_set = int(sum(bin(int(x) & 0xFFFFFFFFFFFFFFFF).count("1") for x in (last[0] | last[1]).flatten().tolist()))
     evals_total = float(P) * T * world * args.steps
     value = evals_total / dt
 
@@ -212,6 +248,7 @@ def main():
                                    "select_words thr %.2f + find_target_match thr %.2f, amplicon 80-200"
                                    % (args.config, T, L, P, select_thr, thr_t),
                        "targets_per_gpu": T, "target_len": L, "pairs": P, "sharding": "targets x%d" % world,
+                       "exchange": ("all_gather_into_tensor of [%d passes, 2, P, words] u64 per rank, pipelined" % K) if use_dist else "none",
                        "amplification_calls_set_rank0": n_set},
             "roofline": {"bound": "hbm",
                          "kernel": ("k_seed (seed-filter oligo x window match scan)" if select_thr >= 0.85
@@ -227,7 +264,7 @@ def main():
             scr.close()
             out["cpu_baseline"] = cpu_baseline(wl, thr_t, mult, args.cpu_seconds)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

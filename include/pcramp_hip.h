@@ -133,6 +133,20 @@ int pcr_screen_device(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32
 	int optimize_5, int optimize_3, float select_threshold, uint32_t min_oligo_length,
 	const pcr_amplify_args *args, uint64_t *d_bits_fr, uint64_t *d_bits_rf);
 
+/* One local-search move, evaluated as optimize_pcr.cpp does for each of its six moves (e.g.
+ * increase_degeneracy :57-100; the loop of optimize(), optimize.cpp:120-140, calls them per oligo):
+ * the candidate amplicons are those of the BASE pair -- collected at args->collect_threshold
+ * (= target_threshold*search_multiplier, optimize.cpp:61-63, assay.h:405-408) against the word DB of
+ * the last pcr_select_words -- and for every variant of the edited oligo (side 0 = F, 1 = R) only that
+ * oligo's identity table is recomputed (update_identity, optimize.cpp:209-261: the variant's own
+ * length and 3' bases) before compute_coverage at args->ident_threshold (pcr_assay.cpp:271-302).
+ *   variants  : n_variants trial words (as the move leaves them, not re-centred)
+ *   bits_fr / bits_rf : n_variants x pcr_bitset_words u64, per orientation as pcr_amplify.  May be NULL.
+ *   coverage  : n_variants floats = compute_target_coverage of each trial.  May be NULL. */
+int pcr_move_coverage(pcr_ctx *ctx, pcr_set which, const pcr_pair *base, int side,
+	const pcr_word128 *variants, uint32_t n_variants, const pcr_amplify_args *args,
+	uint64_t *bits_fr, uint64_t *bits_rf, float *coverage);
+
 /* compute_coverage's weight sum (pcr_assay.cpp:280-301) from gathered orientation bitsets:
  * ascending index over bits_fr, then ascending index over bits_rf & ~bits_fr, accumulated in
  * double; n = number of sequences, weights[n].  Pure host arithmetic (no device needed). */

@@ -625,6 +625,43 @@ float orc_session_target_coverage(orc_session *s, const uint64_t pair[4])
 	catch(const char *e){ s->err = e; return -1.0f; }
 }
 
+// One local-search move evaluated the way optimize_pcr.cpp does it (e.g. :61-100 for +degeneracy; the
+// other five moves follow the same pattern): the candidate amplicons are those of the BASE pair,
+// collected at target_threshold*search_multiplier (optimize.cpp:61-63, assay.h:405-408); for a variant
+// of one oligo only that oligo's identity table is recomputed (update_identity with the variant word:
+// its own length, its own 3' bases), then compute_coverage at target_threshold (pcr_assay.cpp:271-302).
+// orient_out[v*T + i]: bit 0 = sequence i amplified through an {F(+),R(-)} candidate, bit 1 = {R(+),F(-)}.
+int orc_session_move_coverage(orc_session *s, const uint64_t base[4], int side, const uint64_t *variants, unsigned n_variants,
+	float *cov_out, unsigned char *orient_out)
+{
+	try{
+		const W F = load_word(base), R = load_word(base + 2);
+		const size_t T = s->seq.size();
+		std::vector<Amplicon> amp;
+		std::map<uint32_t, float> fi, ri;
+		collect_candidates(amp, fi, ri, F, R, *s, s->opt.target_threshold*s->opt.search_multiplier, s->opt.amp_min, s->opt.amp_max);
+		update_identity(fi, F, s->keys, s->opt.use_taq_mama != 0);               // update_target_candidates, assay.h:436-440
+		update_identity(ri, R, s->keys, s->opt.use_taq_mama != 0);
+		if(orient_out) memset(orient_out, 0, T*n_variants);
+		for(unsigned v = 0;v < n_variants;++v){
+			const W var = load_word(variants + 2*v);
+			update_identity(side == 0 ? fi : ri, var, s->keys, s->opt.use_taq_mama != 0);
+			double ret = 0.0;
+			std::unordered_set<uint32_t> valid;
+			for(const Amplicon &a : amp){
+				const float local = sqrtf(fi[a.f]*ri[a.r]);
+				if(local >= s->opt.target_threshold){
+					if(orient_out) orient_out[(size_t)v*T + a.index] |= a.orient;
+					if(valid.find(a.index) == valid.end()){ valid.insert(a.index); ret += a.weight; }
+				}
+			}
+			cov_out[v] = amp.empty() ? 0.0f : (float)ret;
+		}
+		return 0;
+	}
+	catch(const char *e){ s->err = e; return -1; }
+}
+
 float orc_weighted_coverage(orc_session *s, const unsigned char *bits)            // main.cpp:1402-1418
 {
 	double ret = 0.0;

@@ -78,6 +78,10 @@ int orc_session_target_match(orc_session *s, const uint64_t pair[4], unsigned ch
 // optimize.cpp:61-74: collect (search threshold) + update_identity + compute_coverage.
 float orc_session_target_coverage(orc_session *s, const uint64_t pair[4]);
 // main.cpp:1402-1418
+// optimize_pcr.cpp move evaluation: coverage of each variant of one oligo (side 0 = F, 1 = R) over the
+// BASE pair's candidate amplicons
+int orc_session_move_coverage(orc_session *s, const uint64_t base[4], int side, const uint64_t *variants,
+	unsigned n_variants, float *cov_out, unsigned char *orient_out);
 float orc_weighted_coverage(orc_session *s, const unsigned char *bits);
 
 // ---- Smith-Waterman (SO::SeqOverlap, SmithWaterman + nucleic-acid mode; seq_overlap.cpp:347-609)

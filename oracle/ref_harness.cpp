@@ -338,6 +338,29 @@ float ref_session_target_coverage(RefSession *s, const uint64_t pair[4])
 	catch(...){ s->last_error = "unknown"; return -2.0f; }
 }
 
+// A local-search move as optimize_pcr.cpp evaluates it (:77-93 and the same lines of the other moves):
+// candidates of the base assay (collected by optimize(), optimize.cpp:61-70), identity table of the
+// modified oligo recomputed for the trial word, compute_target_coverage.
+int ref_session_move_coverage(RefSession *s, const uint64_t base[4], int side, const uint64_t *variants,
+	unsigned n_variants, float *cov_out)
+{
+	try{
+		PCR p;
+		p.oligo( FORWARD, word_from(base) );
+		p.oligo( REVERSE, word_from(base + 2) );
+		p.collect_target_candidates(s->target_keys, s->target_db, s->target_seq, s->opt);
+		p.update_target_candidates(s->target_keys, s->opt.use_taq_mama);
+		for(unsigned v = 0;v < n_variants;++v){
+			const Word trial = word_from(variants + 2*v);
+			update_identity( (side == 0) ? p.target_f_identity : p.target_r_identity, trial, s->target_keys, s->opt.use_taq_mama );
+			cov_out[v] = p.compute_target_coverage(s->opt.target_threshold);
+		}
+		return 0;
+	}
+	catch(const char *e){ s->last_error = e; return -1; }
+	catch(...){ s->last_error = "unknown"; return -2; }
+}
+
 // ---------------------------------------------------------------- Smith-Waterman (seq_overlap)
 // One 8-lane call exactly as background_match.cpp drives it: queries/targets are arrays of
 // SO_LEN 64-bit-pair Words (slot i of each).  Outputs per lane: score, query range, target

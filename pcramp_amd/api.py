@@ -74,7 +74,7 @@ _LIB = None
 # every symbol include/pcramp_hip.h declares
 ABI_SYMBOLS = [
     "pcr_last_error", "pcr_create", "pcr_destroy", "pcr_load_sequences", "pcr_set_active", "pcr_split",
-    "pcr_select_words", "pcr_get_entries", "pcr_amplify", "pcr_amplify_device", "pcr_screen_device", "pcr_coverage_from_bits",
+    "pcr_select_words", "pcr_get_entries", "pcr_amplify", "pcr_amplify_device", "pcr_screen_device", "pcr_move_coverage", "pcr_coverage_from_bits",
     "pcr_weighted_coverage", "pcr_num_sequences", "pcr_bitset_words", "pcr_profile_enable", "pcr_profile_read",
     "pcr_synchronize", "pcr_host_irregular_words", "pcr_host_window_valid", "pcr_host_candidates",
     "pcr_host_orientation_seeds",
@@ -132,6 +132,8 @@ def load_library():
     L.pcr_host_candidates.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_uint64]
     L.pcr_screen_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_float, C.c_uint32,
                                     C.POINTER(AmplifyArgs), C.c_void_p, C.c_void_p]
+    L.pcr_move_coverage.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.POINTER(AmplifyArgs),
+                                    C.c_void_p, C.c_void_p, C.c_void_p]
     L.pcr_host_orientation_seeds.restype = C.c_int64
     L.pcr_host_orientation_seeds.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
     _LIB = L
@@ -326,6 +328,25 @@ class Screener:
         self._check(self.L.pcr_screen_device(self.h, which, a.ctypes.data, a.shape[0], int(optimize_5), int(optimize_3),
                                              select_threshold, min_oligo_length, C.byref(args),
                                              C.c_void_p(d_fr_ptr), C.c_void_p(d_rf_ptr)))
+
+    def move_coverage(self, base_pair, side, variants, target_threshold=1.0, search_multiplier=0.9, amp_min=80, amp_max=200,
+                      use_taq_mama=False, which=TARGET):
+        """optimize_pcr.cpp move evaluation: every variant of one oligo (side 0 = F, 1 = R) over the base pair's
+        candidate amplicons -> (coverage float32[n_variants], bits_fr bool[n_variants, n], bits_rf)."""
+        a = W.pairs_array([base_pair])
+        v = np.array([[int(w[0]), int(w[1])] for w in variants], dtype=np.uint64).reshape(-1, 2)
+        V = v.shape[0]
+        nw = int(self.bitset_words(which))
+        n = self.num_sequences(which)
+        fr = np.zeros((max(V, 1), nw), np.uint64)
+        rf = np.zeros((max(V, 1), nw), np.uint64)
+        cov = np.zeros(max(V, 1), np.float32)
+        ct = float(np.float32(target_threshold) * np.float32(search_multiplier))
+        args = AmplifyArgs(ct, target_threshold, amp_min, amp_max, int(use_taq_mama))
+        self._check(self.L.pcr_move_coverage(self.h, which, a.ctypes.data, int(side), v.ctypes.data, V, C.byref(args),
+                                             fr.ctypes.data, rf.ctypes.data, cov.ctypes.data))
+        tb = lambda x: np.stack([bits_to_bool(x[i], n) for i in range(V)]) if V else np.zeros((0, n), bool)
+        return cov[:V], tb(fr), tb(rf)
 
     # -- the two reference evaluations, with Options-style arguments
     def find_target_match(self, pairs, target_threshold=1.0, amp_min=80, amp_max=200, use_taq_mama=False, which=TARGET):

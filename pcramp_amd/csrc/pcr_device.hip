@@ -669,6 +669,62 @@ __global__ void k_pair(const DevEntry *__restrict__ db, uint32_t n, const uint32
 	}
 }
 
+// Local-search move evaluation (optimize_pcr.cpp, e.g. :77-93): the candidate amplicons are those of the
+// BASE pair (masks from k_match over {F, R}; geometry, has_split and the amplicon range from the base
+// oligos, exactly k_pair's sweep); for each variant of the edited oligo (`side`) only that oligo's
+// identity is re-evaluated (update_identity with the variant's own length and 3' bases), the other
+// side keeps the base oligo's.  bits_*[v][seq].
+__global__ void k_pair_moves(const DevEntry *__restrict__ db, uint32_t n, uint32_t cap, const uint32_t *__restrict__ touched,
+	const uint32_t *__restrict__ seg_hi, const uint32_t *__restrict__ mask, const OligoDev *__restrict__ base /* F, R */,
+	const OligoDev *__restrict__ variants, uint32_t n_variants, int side,
+	const uint4 *__restrict__ planes, const uint64_t *__restrict__ blk_off, const uint64_t *__restrict__ len,
+	const uint8_t *__restrict__ active, int32_t amp_min, int32_t amp_max, float ident_thr, int use_taq,
+	uint64_t *__restrict__ bits_fr, uint64_t *__restrict__ bits_rf, uint64_t bit_words, uint32_t *__restrict__ status)
+{
+	const uint32_t t = blockIdx.x*blockDim.x + threadIdx.x;
+	uint32_t i;
+	if(!db_slot(t, n, cap, touched, seg_hi, i)) return;
+	const DevEntry ei = db[i];
+	if(ei.strand != 1) return;
+	if(!active[ei.seq]) return;                                                  // optimize.cpp:281
+	const uint32_t hi = seg_hi[ei.seq];
+	const int32_t L = (int32_t)len[ei.seq];
+	const uint64_t blk_base = blk_off[ei.seq];
+	const OligoDev F = base[0], R = base[1];
+	for(uint32_t j = i + 1;j < hi;++j){
+		const DevEntry ej = db[j];
+		if(ej.loc - ei.loc > amp_max + 128) break;
+		if(ej.strand != 2) continue;
+		const uint32_t mi = mask[i], mj = mask[j];                               // bit 0 = F, bit 1 = R (one mask word)
+		const uint32_t fr = mi & (mj >> 1) & 1u, rf = (mi >> 1) & mj & 1u;
+		for(int orient = 0;orient < 2;++orient){
+			if(!((orient == 0) ? fr : rf)) continue;
+			const OligoDev &P = (orient == 0) ? F : R;   // plus-role oligo
+			const OligoDev &M = (orient == 0) ? R : F;   // minus-role oligo
+			if(ei.loc + P.stop >= ej.loc - M.stop) continue;                     // pcr_assay.cpp:367-370
+			int32_t amp_start = ei.loc + P.start;
+			const int32_t amp_stop = min(ej.loc - M.start, L - 1);
+			int32_t amp_len = amp_stop - amp_start + 1;
+			if(amp_len < amp_min || amp_len > amp_max) continue;
+			if(amp_start < 0){ amp_len += amp_start; amp_start = 0; }
+			if(amp_len < 0 || amp_start + amp_len > L){ atomicOr(status, 1u); continue; }   // sequence.cpp:306 throw
+			if(has_split(planes, blk_base, amp_start, amp_len)) continue;
+			// key matched by F / by R in this orientation
+			const Planes &key_f = (orient == 0) ? ei.w : ej.w;
+			const Planes &key_r = (orient == 0) ? ej.w : ei.w;
+			const float fixed = (side == 0) ? identity(R, key_r, use_taq) : identity(F, key_f, use_taq);
+			const Planes &key_v = (side == 0) ? key_f : key_r;
+			uint64_t *dst = (orient == 0) ? bits_fr : bits_rf;
+			for(uint32_t v = 0;v < n_variants;++v){
+				const float var = identity(variants[v], key_v, use_taq);
+				const float f = (side == 0) ? var : fixed, r = (side == 0) ? fixed : var;
+				if(__fsqrt_rn(__fmul_rn(f, r)) >= ident_thr)                     // pcr_assay.cpp:285-287
+					atomicOr((unsigned long long *)&dst[(size_t)v*bit_words + (ei.seq >> 6)], 1ull << (ei.seq & 63));
+			}
+		}
+	}
+}
+
 #include "pcr_sw.inc"
 #include "pcr_thermo.inc"
 
@@ -1734,6 +1790,61 @@ int pcr_amplify(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 		if(bits_fr) memcpy(bits_fr + p*words, hfr.data() + p*words, words*sizeof(uint64_t));
 		if(bits_rf) memcpy(bits_rf + p*words, hrf.data() + p*words, words*sizeof(uint64_t));
 		if(coverage) coverage[p] = pcr_coverage_from_bits(hfr.data() + p*words, hrf.data() + p*words, S.weight.data(), S.n);
+	}
+	return PCR_OK;
+}
+
+int pcr_move_coverage(pcr_ctx *ctx, pcr_set which, const pcr_pair *base, int side, const pcr_word128 *variants, uint32_t n_variants,
+	const pcr_amplify_args *args, uint64_t *bits_fr, uint64_t *bits_rf, float *coverage)
+{
+	if(!ctx || !args || !base || (side != 0 && side != 1) || (n_variants && !variants)){ g_err = "pcr_move_coverage: bad argument"; return PCR_ERR_ARG; }
+	DRAIN(ctx);
+	HIP_TRY(hipSetDevice(ctx->device));
+	SeqSet &S = ctx->sets[which];
+	if(!S.have_db){ g_err = "pcr_move_coverage: no word DB (call pcr_select_words first)"; return PCR_ERR_STATE; }
+	const uint64_t words = (S.n + 63)/64;
+	const size_t total = (size_t)n_variants*words;
+	if(coverage){ for(uint32_t v = 0;v < n_variants;++v) coverage[v] = 0.0f; }
+	if(bits_fr && total) memset(bits_fr, 0, total*sizeof(uint64_t));
+	if(bits_rf && total) memset(bits_rf, 0, total*sizeof(uint64_t));
+	if(S.n_entries == 0 || n_variants == 0) return PCR_OK;
+	int rc;
+	// oligo table: base F, base R (floors from the collect threshold, pcr_assay.cpp:31-32), then the variants
+	const float thr2 = args->collect_threshold*args->collect_threshold;
+	std::vector<OligoDev> ol(2 + (size_t)n_variants);
+	fill_oligo(ol[0], base->f.w, thr2);
+	fill_oligo(ol[1], base->r.w, thr2);
+	for(uint32_t v = 0;v < n_variants;++v){
+		if((variants[v].w[0] | variants[v].w[1]) == 0){ g_err = "pcr_move_coverage: empty trial oligo"; return PCR_ERR_ARG; }
+		fill_oligo(ol[2 + v], variants[v].w, thr2);
+	}
+	if((rc = ctx->bits_fr.ensure(total + 2)) != PCR_OK) return rc;
+	if((rc = ctx->bits_rf.ensure(total + 2)) != PCR_OK) return rc;
+	Stager st(ctx);
+	if((rc = st.begin(ol.size()*sizeof(OligoDev) + 64)) != PCR_OK) return rc;
+	const OligoDev *d_ol = st.put(ol.data(), ol.size());
+	if((rc = st.ship(ctx->bits_fr.p, total*sizeof(uint64_t), ctx->bits_rf.p, total*sizeof(uint64_t))) != PCR_OK) return rc;
+	if((rc = ctx->mask.ensure((size_t)S.n_slots)) != PCR_OK) return rc;
+	if((rc = ctx->status.ensure(1)) != PCR_OK) return rc;
+	const uint32_t n_db = S.n_touched*S.db_cap;
+	hipLaunchKernelGGL(k_match, dim3((S.n_touched + MATCH_WAVES - 1)/MATCH_WAVES), dim3(64*MATCH_WAVES), 0, ctx->stream, S.db.p, S.n_touched, (const uint32_t *)nullptr, S.db_cap,
+		S.touched.p, S.d_seg_hi, d_ol, 2u, 1u, ctx->mask.p, ctx->status.p, (const uint32_t *)nullptr, (PassMail *)nullptr, 0u);
+	HIP_TRY(hipGetLastError());
+	hipLaunchKernelGGL(k_pair_moves, dim3((n_db + 127)/128), dim3(128), 0, ctx->stream, S.db.p, n_db, S.db_cap, S.touched.p, S.d_seg_hi, ctx->mask.p,
+		d_ol, d_ol + 2, n_variants, side, S.planes.p, S.d_blk_off.p, S.d_len.p, S.d_active.p, args->amp_min, args->amp_max,
+		args->ident_threshold, args->use_taq_mama, ctx->bits_fr.p, ctx->bits_rf.p, words, ctx->status.p);
+	HIP_TRY(hipGetLastError());
+	std::vector<uint64_t> hfr(total), hrf(total);
+	uint32_t status = 0;
+	HIP_TRY(hipMemcpyAsync(hfr.data(), ctx->bits_fr.p, total*sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(hipMemcpyAsync(hrf.data(), ctx->bits_rf.p, total*sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(hipMemcpyAsync(&status, ctx->status.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	if(status & 1u){ g_err = "Sequence::has_split: range is out of bounds"; return PCR_ERR_RANGE; }   // sequence.cpp:306-308
+	for(uint32_t v = 0;v < n_variants;++v){
+		if(bits_fr) memcpy(bits_fr + v*words, hfr.data() + v*words, words*sizeof(uint64_t));
+		if(bits_rf) memcpy(bits_rf + v*words, hrf.data() + v*words, words*sizeof(uint64_t));
+		if(coverage) coverage[v] = pcr_coverage_from_bits(hfr.data() + v*words, hrf.data() + v*words, S.weight.data(), S.n);
 	}
 	return PCR_OK;
 }

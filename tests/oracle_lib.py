@@ -341,6 +341,28 @@ class Session:
         a = pairs_array([pair])
         return self.f("session_target_coverage")(self.h, a.ctypes.data)
 
+    def move_coverage(self, base_pair, side, variants, orient=False):
+        """optimize_pcr.cpp move evaluation: coverage of every variant of one oligo (side 0 = F, 1 = R)
+        over the base pair's candidate amplicons -> float32[n_variants] (oracle: optionally the
+        per-sequence orientation bits uint8[n_variants, n])."""
+        a = pairs_array([base_pair])
+        v = np.array([[int(w[0]), int(w[1])] for w in variants], dtype=np.uint64).reshape(-1, 2)
+        cov = np.zeros(max(len(variants), 1), dtype=np.float32)
+        if isinstance(self.L, Oracle):
+            ori = np.zeros((max(len(variants), 1), max(self.n, 1)), dtype=np.uint8)
+            fn = self.L.lib.orc_session_move_coverage
+            fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p]
+            rc = fn(self.h, a.ctypes.data, int(side), v.ctypes.data, len(variants), cov.ctypes.data, ori.ctypes.data)
+            if rc != 0:
+                raise RuntimeError(self.f("session_error")(self.h))
+            return (cov[:len(variants)], ori[:len(variants), :self.n]) if orient else cov[:len(variants)]
+        fn = self.L.lib.ref_session_move_coverage
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_uint, C.c_void_p]
+        rc = fn(self.h, a.ctypes.data, int(side), v.ctypes.data, len(variants), cov.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(self.f("session_error")(self.h))
+        return cov[:len(variants)]
+
     def background_match(self, pair, bg_threshold=0.8, bg_multiplier=0.9, amp_min=0, amp_max=2000, use_taq_mama=0,
                          emulate_index_bug=0):
         """-> (bits uint8[n], n_amplicons or None).  Reference: returns None bits when the reference's

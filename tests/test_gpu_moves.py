@@ -1,0 +1,78 @@
+"""pcr_move_coverage (local-search move evaluation, optimize_pcr.cpp) against the oracle: coverage floats
+and per-orientation bits of every single-edit variant, bit-exact.  Run on the GPU box with `-m gpu`."""
+import random
+
+import numpy as np
+import pytest
+
+from pcramp_amd import api, words as W
+from testdata import family_targets, sample_pair, move_variants
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(target_threshold=0.9), dict(target_threshold=0.85, use_taq_mama=1)])
+def test_move_coverage_matches_oracle(oracle, opts):
+    o = dict(target_threshold=1.0, search_multiplier=0.9, amp_min=80, amp_max=200, use_taq_mama=0,
+             pack_max_degen=256, pack_min_gc=0.0, pack_max_gc=1.0, min_primer=18, optimize_5=0, optimize_3=0)
+    o.update(opts)
+    rng = random.Random(177 + len(opts))
+    seqs = family_targets(rng, 4, 10, 900, div=0.05)
+    weights = [1.0 + 0.21 * (i % 7) for i in range(len(seqs))]
+    pairs_txt = []
+    while len(pairs_txt) < 8:
+        p = sample_pair(rng, rng.choice(seqs))
+        if p:
+            pairs_txt.append(p)
+    pairs = [(oracle.centered_word(f), oracle.centered_word(r)) for f, r in pairs_txt]
+    so = oracle.session(**o)
+    for s, w in zip(seqs, weights):
+        so.add_target(s, w)
+    so.select(pairs)
+    d = api.Screener(0)
+    try:
+        d.load_texts(seqs, weights)
+        thr = float(np.float32(o["target_threshold"]) * np.float32(o["search_multiplier"]))
+        d.select_words(pairs, thr, o["min_primer"])
+        n_checked = n_nonzero = 0
+        for p in pairs:
+            for side in (0, 1):
+                var = []
+                for kind in ("inc", "trim5", "trim3", "grow5", "grow3"):
+                    var += move_variants(W, p[side], kind)
+                var += [v2 for v in var[:6] for v2 in move_variants(W, v, "dec")]
+                co, oo = so.move_coverage(p, side, var, orient=True)
+                cd, fr, rf = d.move_coverage(p, side, var, o["target_threshold"], o["search_multiplier"], o["amp_min"],
+                                             o["amp_max"], bool(o["use_taq_mama"]))
+                assert np.array_equal(cd, co)
+                assert np.array_equal(fr, (oo & 1) != 0)
+                assert np.array_equal(rf, (oo & 2) != 0)
+                n_checked += len(var)
+                n_nonzero += int(np.count_nonzero(co))
+        assert n_checked > 500 and n_nonzero > 50
+    finally:
+        d.close()
+
+
+def test_move_coverage_of_the_base_word_is_compute_coverage(oracle):
+    """The unedited oligo as its own 'variant' gives compute_coverage of the pair."""
+    rng = random.Random(5)
+    seqs = family_targets(rng, 3, 8, 800, div=0.04)
+    pairs_txt = []
+    while len(pairs_txt) < 5:
+        p = sample_pair(rng, rng.choice(seqs))
+        if p:
+            pairs_txt.append(p)
+    pairs = [(oracle.centered_word(f), oracle.centered_word(r)) for f, r in pairs_txt]
+    d = api.Screener(0)
+    try:
+        d.load_texts(seqs, [1.0] * len(seqs))
+        thr = float(np.float32(1.0) * np.float32(0.9))
+        d.select_words(pairs, thr, 18)
+        cov = d.compute_coverage(pairs, 1.0, 0.9, 80, 200, False)
+        for k, p in enumerate(pairs):
+            for side in (0, 1):
+                c, _, _ = d.move_coverage(p, side, [p[side]], 1.0, 0.9, 80, 200, False)
+                assert c[0] == cov[k]
+    finally:
+        d.close()

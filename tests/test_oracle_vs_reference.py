@@ -346,3 +346,36 @@ def test_is_valid_and_dimer_filters(oracle, reference):
         r2 = reference.centered_word(revcomp(rand_seq(rng, 6) + "ACGTTGCAAT" + rand_seq(rng, 5)))
         for md in (10.0, 25.0, 40.0):
             assert oracle.multiplex_compatible((f, r), (f2, r2), max_dimer=md) == reference.multiplex_compatible((f, r), (f2, r2), max_dimer=md)
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(target_threshold=0.9), dict(target_threshold=0.85, use_taq_mama=1)])
+def test_move_coverage(oracle, reference, opts):
+    """The coverage of every single-edit variant of an oligo, evaluated as optimize_pcr.cpp does (base pair's
+    candidate amplicons, identity table of the edited oligo recomputed): oracle == compiled reference."""
+    from pcramp_amd import words as W
+    from testdata import move_variants
+    rng = random.Random(77 + len(opts))
+    seqs = family_targets(rng, 3, 8, 700, div=0.05)
+    weights = [1.0 + 0.21 * (i % 7) for i in range(len(seqs))]
+    pairs_txt = []
+    while len(pairs_txt) < 6:
+        p = sample_pair(rng, rng.choice(seqs))
+        if p:
+            pairs_txt.append(p)
+    pairs = [(reference.centered_word(f), reference.centered_word(r)) for f, r in pairs_txt]
+    so, sr = _sessions(oracle, reference, seqs, weights, **opts)
+    assert so.select(pairs) == sr.select(pairs)
+    n_checked = n_nonzero = 0
+    for p in pairs:
+        for side in (0, 1):
+            var = []
+            for kind in ("inc", "trim5", "trim3", "grow5", "grow3"):
+                var += move_variants(W, p[side], kind)
+            # second-order edits so that 'dec' has something to remove
+            var += [v2 for v in var[:6] for v2 in move_variants(W, v, "dec")]
+            co = so.move_coverage(p, side, var)
+            cr = sr.move_coverage(p, side, var)
+            assert np.array_equal(co, cr)
+            n_checked += len(var)
+            n_nonzero += int(np.count_nonzero(co))
+    assert n_checked > 500 and n_nonzero > 50

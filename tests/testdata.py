@@ -59,3 +59,38 @@ def sample_pair(rng, seq, primer=(18, 25), amplicon=(80, 200)):
             continue
         return f, r
     return None
+
+
+def move_variants(W, word, kind, rng=None, context=None):
+    """Single-edit variants of an oligo word in the spirit of the reference's local-search moves
+    (optimize_pcr.cpp): 'inc' = add one base bit at one occupied slot (increase_degeneracy :57-70),
+    'dec' = remove one base bit from a degenerate slot (decrease_degeneracy), 'trim5'/'trim3' = drop the
+    first / last occupied slot, 'grow5'/'grow3' = occupy the next slot towards 5'/3' with one of the
+    four bases.  Words are returned as the reference leaves them before re-centring (slots unmoved).
+    W = pcramp_amd.words module."""
+    slots = [int(v) for v in W.slots_from_word(word)]
+    occ = [k for k in range(32) if slots[k]]
+    first, last = occ[0], occ[-1]
+    out = []
+    if kind == "inc":
+        for k in occ:
+            for b in (1, 2, 4, 8):
+                if not (slots[k] & b):
+                    t = list(slots); t[k] |= b; out.append(W.word_from_slots(t))
+    elif kind == "dec":
+        for k in occ:
+            if bin(slots[k]).count("1") > 1:
+                for b in (1, 2, 4, 8):
+                    if slots[k] & b:
+                        t = list(slots); t[k] &= ~b; out.append(W.word_from_slots(t))
+    elif kind == "trim5":
+        t = list(slots); t[first] = 0; out.append(W.word_from_slots(t))
+    elif kind == "trim3":
+        t = list(slots); t[last] = 0; out.append(W.word_from_slots(t))
+    elif kind == "grow5" and first > 0:
+        for b in (1, 2, 4, 8):
+            t = list(slots); t[first - 1] = b; out.append(W.word_from_slots(t))
+    elif kind == "grow3" and last < 31:
+        for b in (1, 2, 4, 8):
+            t = list(slots); t[last + 1] = b; out.append(W.word_from_slots(t))
+    return out
