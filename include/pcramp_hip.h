@@ -271,6 +271,15 @@ int64_t pcr_host_candidates(const pcr_pair *pairs, uint32_t n_pairs, int optimiz
 int64_t pcr_host_orientation_seeds(const pcr_word128 *oligo, uint32_t floor, uint32_t *codes, uint8_t *q,
 	uint8_t *off, uint64_t cap);
 
+/* The trial words of one local-search move of optimize_pcr.cpp for `oligo`, in the reference's order and
+ * after its degeneracy / length gates (increase_degeneracy :17-19,:54-76; decrease_degeneracy :232-247;
+ * trim5/trim3 :391-399; grow5/grow3 :671-673,:709-713), before is_valid (pcr_thermo) and the coverage
+ * evaluation (pcr_move_coverage).  move: PCR_MOVE_*.  Host only.  Returns the count (may exceed cap). */
+enum { PCR_MOVE_INCREASE_DEGENERACY = 0, PCR_MOVE_DECREASE_DEGENERACY = 1, PCR_MOVE_TRIM5 = 2, PCR_MOVE_TRIM3 = 3,
+       PCR_MOVE_GROW5 = 4, PCR_MOVE_GROW3 = 5 };
+int64_t pcr_host_move_trials(const pcr_word128 *oligo, int move, double max_degen, int primer_min, int primer_max,
+	pcr_word128 *trials_out, uint64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

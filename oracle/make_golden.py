@@ -200,12 +200,54 @@ def thermo_golden(ref):
     return {"oligos": oligos, "hetero": hetero, "is_valid": filt, "dimers": dimers}
 
 
+def moves_golden(ref):
+    """The six local-search moves of optimize_pcr.cpp run by the reference's optimization_move() for both
+    oligos of a few assays (targets + backgrounds, non-multiplex): returned trial word and Score."""
+    from oracle_lib import optimization_move, DEFAULT_MOVE_OPTIONS
+    from testdata import mutate
+    cases = []
+    for ci, case in enumerate([dict(), dict(degen=16), dict(target_threshold=0.9, degen=4, use_taq_mama=1)]):
+        case = dict(case)
+        sess = {k: case.pop(k) for k in ("target_threshold", "use_taq_mama") if k in case}
+        rng = random.Random(909 + ci)
+        seqs = family_targets(rng, 2, 6, 420, div=0.06)
+        bgs = [mutate(rng, q, 0.12) for q in seqs[::3]] + [rand_seq(rng, 300)]
+        weights = [1.0 + 0.3 * (i % 4) for i in range(len(seqs))]
+        pairs_txt = []
+        while len(pairs_txt) < 4:
+            p = sample_pair(rng, rng.choice(seqs))
+            if p:
+                pairs_txt.append(p)
+        f, r = pairs_txt[0]
+        f = list(f); f[rng.randrange(3, len(f) - 3)] = rng.choice("RYKM")
+        pairs_txt.append(("".join(f), r))
+        pairs = [(ref.centered_word(a), ref.centered_word(b)) for a, b in pairs_txt]
+        ts, bs = ref.session(**sess), ref.session(**sess)
+        for q, wt in zip(seqs, weights):
+            ts.add_target(q, wt)
+        for q in bgs:
+            bs.add_target(q, 1.0)
+        ts.select(pairs)
+        bs.select(pairs, threshold=0.8 * 0.9, min_len_override=16)
+        out = []
+        for pi, p in enumerate(pairs):
+            for side in (0, 1):
+                for move in range(6):
+                    w, sc, base = optimization_move(ref, ts, bs, p, move, side, **case)
+                    out.append([pi, side, move, hexw(w), list(sc), list(base)])
+        mo = dict(DEFAULT_MOVE_OPTIONS); mo.update(case)
+        cases.append({"options": ts.opts, "move_options": mo, "seqs": seqs, "weights": weights, "backgrounds": bgs,
+                      "bg_select_threshold": 0.8 * 0.9, "bg_min_len": 16,
+                      "pairs": [hexw(a) + hexw(b) for a, b in pairs], "moves": out})
+    return {"cases": cases}
+
+
 def main():
     build_reference()
     ref = Reference()
     os.makedirs(OUT, exist_ok=True)
     for name, fn in (("words", words_golden), ("pack", pack_golden), ("screen", screen_golden), ("sw", sw_golden),
-                     ("thermo", thermo_golden)):
+                     ("thermo", thermo_golden), ("moves", moves_golden)):
         with open(os.path.join(OUT, name + ".json"), "w") as f:
             json.dump(fn(ref), f, separators=(",", ":"))
         print("wrote", name, os.path.getsize(os.path.join(OUT, name + ".json")), "bytes")

@@ -662,6 +662,106 @@ int orc_session_move_coverage(orc_session *s, const uint64_t base[4], int side, 
 	catch(const char *e){ s->err = e; return -1; }
 }
 
+extern "C" int orc_is_valid(const uint64_t word[2], float salt, float primer_strand, float tm_min, float tm_max,
+	float max_hairpin, float max_dimer, int check_homo_dimer);
+
+namespace {
+// compute_coverage (pcr_assay.cpp:271-302)
+float coverage_of(const std::vector<Amplicon> &amp, std::map<uint32_t, float> &fi, std::map<uint32_t, float> &ri, float thr)
+{
+	if(amp.empty()) return 0;
+	double ret = 0.0;
+	std::unordered_set<uint32_t> valid;
+	for(const Amplicon &a : amp){
+		const float local = sqrtf(fi[a.f]*ri[a.r]);
+		if(local >= thr && valid.find(a.index) == valid.end()){ valid.insert(a.index); ret += a.weight; }
+	}
+	return (float)ret;
+}
+struct ScoreO {                                                                   // pcramp.h:158-208
+	float tc = -1.0e6f, bc = 1.0e6f, ov = 0.0f;
+	float accuracy() const { return tc - bc; }
+	bool gt(const ScoreO &r) const { return (accuracy() == r.accuracy()) ? (ov > r.ov) : (accuracy() > r.accuracy()); }
+};
+}
+
+int orc_optimization_move(orc_session *t, orc_session *b, const uint64_t pair[4], int move, int side,
+	const orc_move_options *mo, uint64_t out_word[2], float out_score[3], float base_score_out[2])
+{
+	try{
+		const W F = load_word(pair), R = load_word(pair + 2);
+		const bool taq = t->opt.use_taq_mama != 0;
+		// optimize.cpp:61-79: candidates and identity tables of the base assay, base score
+		std::vector<Amplicon> tamp, bamp;
+		std::map<uint32_t, float> tfi, tri, bfi, bri;
+		collect_candidates(tamp, tfi, tri, F, R, *t, t->opt.target_threshold*t->opt.search_multiplier, t->opt.amp_min, t->opt.amp_max);
+		if(b && !b->keys.empty())                                                     // assay.h:411-421
+			collect_candidates(bamp, bfi, bri, F, R, *b, mo->bg_threshold*mo->bg_multiplier, mo->bg_amp_min, mo->bg_amp_max);
+		update_identity(tfi, F, t->keys, taq); update_identity(tri, R, t->keys, taq);
+		if(b){ update_identity(bfi, F, b->keys, taq); update_identity(bri, R, b->keys, taq); }
+		ScoreO base;
+		base.tc = coverage_of(tamp, tfi, tri, t->opt.target_threshold);
+		base.bc = coverage_of(bamp, bfi, bri, mo->bg_threshold);
+		if(base_score_out){ base_score_out[0] = base.tc; base_score_out[1] = base.bc; }
+		const W cur = side == 0 ? F : R;
+		// the trial words, in the reference's order, after its cheap gates (before is_valid)
+		std::vector<W> trials;
+		const int len = (int)cur.size();
+		switch(move){
+			case 0:                                                                   // increase_degeneracy, optimize_pcr.cpp:17-19,54-76
+				if(cur.degeneracy() >= mo->degen) break;
+				for(int i = cur.start();i <= cur.stop();++i){
+					for(unsigned bb = 1;bb <= 8;bb <<= 1){
+						if(cur.get(i) & bb) continue;
+						W w = cur; w.set(cur.get(i) | bb, i);
+						if(w.degeneracy() > mo->degen) continue;
+						trials.push_back(w);
+					}
+				}
+				break;
+			case 1:                                                                   // decrease_degeneracy, :232-247
+				for(int i = cur.start();i <= cur.stop();++i){
+					const unsigned c = cur.get(i);
+					for(unsigned bb = 1;bb <= 8;bb <<= 1){
+						const unsigned d = c & ~bb;
+						if(!d || d == c) continue;
+						W w = cur; w.set(d, i); trials.push_back(w);
+					}
+				}
+				break;
+			case 2: if(len != mo->primer_min){ W w = cur; if(w.start() < 32) w.set(0, w.start()); trials.push_back(w); } break;   // trim5 :391-399, word.h:355
+			case 3: if(len != mo->primer_min){ W w = cur; if(w.stop() >= 0) w.set(0, w.stop()); trials.push_back(w); } break;    // trim3, word.h:364
+			case 4:                                                                   // grow5 :671-673,709-713, word.h:374
+				if(len == mo->primer_max) break;
+				for(unsigned bb = 1;bb <= 8;bb <<= 1){ W w = cur; const int i = w.start() - 1; if(i >= 0) w.set(bb, i); trials.push_back(w); }
+				break;
+			case 5:                                                                   // grow3, word.h:383
+				if(len == mo->primer_max) break;
+				for(unsigned bb = 1;bb <= 8;bb <<= 1){ W w = cur; const int i = w.stop() + 1; if(i < 32) w.set(bb, i); trials.push_back(w); }
+				break;
+			default: throw "unknown move";
+		}
+		ScoreO best; W best_w; best_w.b[0] = best_w.b[1] = 0;
+		for(const W &w : trials){
+			const int ok = orc_is_valid(w.b, mo->salt, mo->primer_strand, mo->tm_min, mo->tm_max, mo->max_hairpin, 0.0f, 0);
+			if(ok < 0) throw "is_valid failed";
+			if(!ok) continue;
+			ScoreO tr;                                                                // the reference reuses one trial_score: fields not set below keep defaults only for the first trial;
+			update_identity(side == 0 ? tfi : tri, w, t->keys, taq);                  // a skipped trial never reaches the comparison, so it does not matter
+			tr.tc = coverage_of(tamp, tfi, tri, t->opt.target_threshold);
+			const float bound = tr.tc + base.bc - base.tc;                           // :95-97 (m_score_threshold = the base score)
+			if(bound <= 0.0f) continue;                                               // :102-109 (non-multiplex)
+			if(b) update_identity(side == 0 ? bfi : bri, w, b->keys, taq);
+			tr.bc = coverage_of(bamp, bfi, bri, mo->bg_threshold);
+			if(tr.gt(best)){ best = tr; best_w = w; }
+		}
+		out_word[0] = best_w.b[0]; out_word[1] = best_w.b[1];
+		out_score[0] = best.tc; out_score[1] = best.bc; out_score[2] = best.ov;
+		return 0;
+	}
+	catch(const char *e){ t->err = e; return -1; }
+}
+
 float orc_weighted_coverage(orc_session *s, const unsigned char *bits)            // main.cpp:1402-1418
 {
 	double ret = 0.0;

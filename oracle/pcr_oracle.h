@@ -82,6 +82,23 @@ float orc_session_target_coverage(orc_session *s, const uint64_t pair[4]);
 // BASE pair's candidate amplicons
 int orc_session_move_coverage(orc_session *s, const uint64_t base[4], int side, const uint64_t *variants,
 	unsigned n_variants, float *cov_out, unsigned char *orient_out);
+// One complete local-search move as optimize() runs it for one oligo (optimize.cpp:61-140 +
+// optimize_pcr.cpp): candidates of the base pair on the target session `t` and (optional) background
+// session `b`, the move's trial words in the reference's order with its degeneracy / length gates,
+// is_valid without the dimer check, target coverage, the coverage-bound shortcut, background coverage,
+// Score comparison.  Non-multiplex.  move: 0 +degeneracy, 1 -degeneracy, 2 trim 5', 3 trim 3', 4 grow 5', 5 grow 3'.
+typedef struct {
+	int degen;                       // Options::degen (maximum oligo degeneracy)
+	int primer_min, primer_max;      // Options::primer_range
+	float salt, primer_strand, tm_min, tm_max, max_hairpin;
+	float bg_threshold, bg_multiplier;
+	int bg_amp_min, bg_amp_max;
+} orc_move_options;
+// out_score: target_coverage, background_coverage, oligo_overlap of the returned trial (the Score defaults
+// -1e6, 1e6, 0 and an empty word if no trial survived); base_score_out (may be NULL): the base pair's.
+int orc_optimization_move(orc_session *t, orc_session *b, const uint64_t pair[4], int move, int side,
+	const orc_move_options *mo, uint64_t out_word[2], float out_score[3], float base_score_out[2]);
+
 float orc_weighted_coverage(orc_session *s, const unsigned char *bits);
 
 // ---- Smith-Waterman (SO::SeqOverlap, SmithWaterman + nucleic-acid mode; seq_overlap.cpp:347-609)

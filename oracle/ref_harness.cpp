@@ -361,6 +361,66 @@ int ref_session_move_coverage(RefSession *s, const uint64_t base[4], int side, c
 	catch(...){ s->last_error = "unknown"; return -2; }
 }
 
+// One complete local-search move the way optimize() drives it (optimize.cpp:61-79,126-130): candidates and
+// identity tables of the base assay on the target session and the optional background session, base score
+// as the score threshold, then optimization_move() -- the reference's own move function -- with a fresh
+// NucCruc.  Non-multiplex (empty pool, empty multiplex keys).
+struct RefMoveOptions {
+	int degen; int primer_min, primer_max;
+	float salt, primer_strand, tm_min, tm_max, max_hairpin;
+	float bg_threshold, bg_multiplier; int bg_amp_min, bg_amp_max;
+};
+
+static void prefill(NucCruc &melt);
+
+int ref_optimization_move(RefSession *t, RefSession *b, const uint64_t pair[4], int move, int side,
+	const RefMoveOptions *mo, uint64_t out_word[2], float out_score[3], float base_score_out[2])
+{
+	try{
+		Options opt = t->opt;
+		opt.degen = mo->degen;
+		opt.primer_range = make_pair(mo->primer_min, mo->primer_max);
+		opt.salt = mo->salt; opt.primer_strand = mo->primer_strand;
+		opt.primer_tm_range = make_pair(mo->tm_min, mo->tm_max);
+		opt.max_hairpin = mo->max_hairpin;
+		opt.background_threshold = mo->bg_threshold;
+		opt.background_search_multiplier = mo->bg_multiplier;
+		opt.background_amplicon_range = make_pair(mo->bg_amp_min, mo->bg_amp_max);
+		opt.use_multiplex = false;
+		const vector<Word> no_keys;
+		const MULTIMAP<Word, WordMatch> no_db;
+		const deque<Sequence> no_seq;
+		const vector<Word> &bkeys = b ? b->target_keys : no_keys;
+		PCR p;
+		p.oligo( FORWARD, word_from(pair) );
+		p.oligo( REVERSE, word_from(pair + 2) );
+		p.collect_target_candidates(t->target_keys, t->target_db, t->target_seq, opt);
+		p.collect_background_candidates(bkeys, b ? b->target_db : no_db, b ? b->target_seq : no_seq, opt);
+		p.update_target_candidates(t->target_keys, opt.use_taq_mama);
+		p.update_background_candidates(bkeys, opt.use_taq_mama);
+		Score base;
+		base.target_coverage = p.compute_target_coverage(opt.target_threshold);
+		base.background_coverage = p.compute_background_coverage(opt.background_threshold);
+		if(base_score_out){ base_score_out[0] = base.target_coverage; base_score_out[1] = base.background_coverage; }
+		NucCruc melt;
+		prefill(melt);
+		melt.fast_alignment(true);
+		melt.salt(opt.salt);
+		const deque<PCR> pool;
+		const Move mv[6] = { IncreaseDegeneracy, DecreaseDegeneracy, Trim5, Trim3, Grow5, Grow3 };
+		if(move < 0 || move > 5) throw "unknown move";
+		const std::pair<Word, Score> r = optimization_move(mv[move], (side == 0) ? FORWARD : REVERSE, p,
+			t->target_keys, opt.target_threshold, bkeys, opt.background_threshold, no_keys, base, melt, pool, opt);
+		unsigned char buf[16];
+		r.first.mpi_pack(buf);
+		memcpy(out_word, buf, 16);
+		out_score[0] = r.second.target_coverage; out_score[1] = r.second.background_coverage; out_score[2] = r.second.oligo_overlap;
+		return 0;
+	}
+	catch(const char *e){ t->last_error = e; return -1; }
+	catch(...){ t->last_error = "unknown"; return -2; }
+}
+
 // ---------------------------------------------------------------- Smith-Waterman (seq_overlap)
 // One 8-lane call exactly as background_match.cpp drives it: queries/targets are arrays of
 // SO_LEN 64-bit-pair Words (slot i of each).  Outputs per lane: score, query range, target

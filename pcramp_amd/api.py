@@ -77,7 +77,7 @@ ABI_SYMBOLS = [
     "pcr_select_words", "pcr_get_entries", "pcr_amplify", "pcr_amplify_device", "pcr_screen_device", "pcr_move_coverage", "pcr_coverage_from_bits",
     "pcr_weighted_coverage", "pcr_num_sequences", "pcr_bitset_words", "pcr_profile_enable", "pcr_profile_read",
     "pcr_synchronize", "pcr_host_irregular_words", "pcr_host_window_valid", "pcr_host_candidates",
-    "pcr_host_orientation_seeds",
+    "pcr_host_orientation_seeds", "pcr_host_move_trials",
     "pcr_sw_align_words", "pcr_background_match", "pcr_multiplex_match",
     "pcr_thermo", "pcr_dimer", "pcr_multiplex_compatible",
 ]
@@ -134,6 +134,8 @@ def load_library():
                                     C.POINTER(AmplifyArgs), C.c_void_p, C.c_void_p]
     L.pcr_move_coverage.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.POINTER(AmplifyArgs),
                                     C.c_void_p, C.c_void_p, C.c_void_p]
+    L.pcr_host_move_trials.restype = C.c_int64
+    L.pcr_host_move_trials.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_uint64]
     L.pcr_host_orientation_seeds.restype = C.c_int64
     L.pcr_host_orientation_seeds.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
     _LIB = L
@@ -165,6 +167,17 @@ def host_window_valid(packed, length, pack_max_degen=256, pack_min_gc=0.0, pack_
     if L.pcr_host_window_valid(buf.ctypes.data, length, C.byref(p), out.ctypes.data) != 0:
         raise PcrError(_err(L))
     return out[:length]
+
+
+def host_move_trials(word, move, max_degen=1, primer_min=18, primer_max=25):
+    """Trial words of one optimize_pcr.cpp move (0 +degen, 1 -degen, 2 trim5, 3 trim3, 4 grow5, 5 grow3)."""
+    L = load_library()
+    w = np.array([int(word[0]), int(word[1])], dtype=np.uint64)
+    out = np.zeros((512, 2), dtype=np.uint64)
+    n = L.pcr_host_move_trials(w.ctypes.data, int(move), float(max_degen), int(primer_min), int(primer_max), out.ctypes.data, 512)
+    if n < 0:
+        raise PcrError(_err(L))
+    return [(int(out[i, 0]), int(out[i, 1])) for i in range(int(n))]
 
 
 def host_orientation_seeds(word, floor):

@@ -1970,6 +1970,18 @@ int64_t pcr_host_orientation_seeds(const pcr_word128 *oligo, uint32_t floor, uin
 	return (int64_t)seeds.size();
 }
 
+int64_t pcr_host_move_trials(const pcr_word128 *oligo, int move, double max_degen, int primer_min, int primer_max,
+	pcr_word128 *trials_out, uint64_t cap)
+{
+	if(!oligo){ g_err = "null oligo"; return PCR_ERR_ARG; }
+	std::vector<Planes> t;
+	if(!pcrhost::move_trials(pcrhost::planes_of_word(oligo->w), move, max_degen, primer_min, primer_max, t)){
+		g_err = "pcr_host_move_trials: unknown move"; return PCR_ERR_ARG;
+	}
+	for(size_t i = 0;i < t.size() && i < cap;++i) pcrhost::word_of_planes(t[i], trials_out[i].w);
+	return (int64_t)t.size();
+}
+
 } // extern "C"
 
 // ------------------------------------------------------------------ Smith-Waterman entry points

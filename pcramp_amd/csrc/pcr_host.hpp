@@ -599,5 +599,63 @@ inline bool orientation_seeds(const Planes &m, uint32_t floor_, uint32_t orient,
 	return true;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Trial words of the local-search moves (optimize_pcr.cpp), in the reference's order, after its
+// degeneracy / length gates and before is_valid:
+//   0 increase_degeneracy (:17-19 gate, :54-76): every occupied slot, every base bit not yet set,
+//                          skipped if the trial's degeneracy exceeds max_degen;
+//   1 decrease_degeneracy (:232-247): every occupied slot, every set bit whose removal leaves a
+//                          non-empty, different set;
+//   2 trim5 / 3 trim3     (:391-399): drop the first / last occupied slot unless at primer_min;
+//   4 grow5 / 5 grow3     (:671-673, :709-713): A, C, G, T in the slot before the first / after the
+//                          last (Word::grow_front/back leave the word unchanged if there is no room)
+//                          unless at primer_max.
+// Slots are not re-centred (the reference centres only the accepted word, optimize.cpp:152).
+inline bool move_trials(const Planes &cur, int move, double max_degen, int primer_min, int primer_max, std::vector<Planes> &out)
+{
+	const int first = planes_start(cur), last = planes_stop(cur), len = planes_size(cur);
+	auto with_nibble = [](Planes w, int k, unsigned v){
+		const uint32_t bit = 1u << k;
+		w.a = (w.a & ~bit) | ((v & 1u) ? bit : 0u); w.c = (w.c & ~bit) | ((v & 2u) ? bit : 0u);
+		w.g = (w.g & ~bit) | ((v & 4u) ? bit : 0u); w.t = (w.t & ~bit) | ((v & 8u) ? bit : 0u);
+		return w;
+	};
+	switch(move){
+		case 0:
+			if(planes_degeneracy(cur) >= max_degen) return true;
+			for(int i = first;i <= last;++i){
+				const unsigned c = planes_nibble(cur, i);
+				for(unsigned b = 1;b <= 8;b <<= 1){
+					if(c & b) continue;
+					const Planes w = with_nibble(cur, i, c | b);
+					if(planes_degeneracy(w) > max_degen) continue;
+					out.push_back(w);
+				}
+			}
+			return true;
+		case 1:
+			for(int i = first;i <= last;++i){
+				const unsigned c = planes_nibble(cur, i);
+				for(unsigned b = 1;b <= 8;b <<= 1){
+					const unsigned d = c & ~b;
+					if(!d || d == c) continue;
+					out.push_back(with_nibble(cur, i, d));
+				}
+			}
+			return true;
+		case 2: if(len != primer_min){ out.push_back(first < 32 ? with_nibble(cur, first, 0) : cur); } return true;
+		case 3: if(len != primer_min){ out.push_back(last >= 0 ? with_nibble(cur, last, 0) : cur); } return true;
+		case 4:
+			if(len == primer_max) return true;
+			for(unsigned b = 1;b <= 8;b <<= 1) out.push_back(first - 1 >= 0 && first < 32 ? with_nibble(cur, first - 1, b) : cur);
+			return true;
+		case 5:
+			if(len == primer_max) return true;
+			for(unsigned b = 1;b <= 8;b <<= 1) out.push_back(last + 1 < 32 ? with_nibble(cur, last + 1, b) : cur);
+			return true;
+		default: return false;
+	}
+}
+
 } // namespace pcrhost
 #endif

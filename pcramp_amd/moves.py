@@ -1,0 +1,79 @@
+"""Local-search moves of the reference's optimiser (optimize_pcr.cpp, optimize.cpp:61-140) over the
+device primitives: trial generation on the host (pcr_host_move_trials), PCR::is_valid on the device
+(pcr_thermo, no dimer check), coverage of every surviving trial in one call per sequence set
+(pcr_move_coverage), then the reference's coverage-bound shortcut and Score comparison.
+
+Non-multiplex (empty pool): Score.oligo_overlap stays 0.  The word DBs of the target and background
+sets must have been built for the current trial assays (Screener.select_words on each set), as
+optimize() is called inside main.cpp's per-iteration DB build.
+"""
+import numpy as np
+
+from . import api
+
+INCREASE_DEGENERACY, DECREASE_DEGENERACY, TRIM5, TRIM3, GROW5, GROW3 = range(6)
+
+EMPTY_SCORE = (np.float32(-1.0e6), np.float32(1.0e6), np.float32(0.0))     # Score(), pcramp.h:176-179
+
+
+def _accuracy(sc):
+    return np.float32(sc[0]) - np.float32(sc[1])                            # Score::accuracy, pcramp.h:205
+
+
+def score_gt(a, b):
+    """Score::operator> (pcramp.h:190-197)."""
+    if _accuracy(a) == _accuracy(b):
+        return np.float32(a[2]) > np.float32(b[2])
+    return _accuracy(a) > _accuracy(b)
+
+
+def base_score(scr, pair, target_threshold=1.0, search_multiplier=0.9, amp_min=80, amp_max=200, use_taq_mama=False,
+               bg_threshold=0.8, bg_multiplier=0.9, bg_amp_min=0, bg_amp_max=2000, have_background=True):
+    """(target_coverage, background_coverage) of the unmodified assay, optimize.cpp:72-76."""
+    tc, _, _ = scr.move_coverage(pair, 0, [pair[0]], target_threshold, search_multiplier, amp_min, amp_max, use_taq_mama,
+                                 which=api.TARGET)
+    bc = np.float32(0.0)
+    if have_background:
+        b, _, _ = scr.move_coverage(pair, 0, [pair[0]], bg_threshold, bg_multiplier, bg_amp_min, bg_amp_max, use_taq_mama,
+                                    which=api.BACKGROUND)
+        bc = b[0]
+    return np.float32(tc[0]), np.float32(bc)
+
+
+def optimization_move(scr, pair, move, side, score_threshold=None, degen=1, primer_min=18, primer_max=25, salt=0.05,
+                      primer_strand=9.0e-7, tm_min=50.0, tm_max=70.0, max_hairpin=40.0, target_threshold=1.0,
+                      search_multiplier=0.9, amp_min=80, amp_max=200, use_taq_mama=False, bg_threshold=0.8,
+                      bg_multiplier=0.9, bg_amp_min=0, bg_amp_max=2000, have_background=True):
+    """optimization_move (optimize.cpp:303-352) for one oligo of `pair` (side 0 = F, 1 = R).
+
+    -> (word, (target_coverage, background_coverage, oligo_overlap)); the empty word (0, 0) and Score()
+    if no trial survives, as the reference's move functions return."""
+    kw = dict(target_threshold=target_threshold, search_multiplier=search_multiplier, amp_min=amp_min, amp_max=amp_max,
+              use_taq_mama=use_taq_mama, bg_threshold=bg_threshold, bg_multiplier=bg_multiplier, bg_amp_min=bg_amp_min,
+              bg_amp_max=bg_amp_max, have_background=have_background)
+    if score_threshold is None:
+        score_threshold = base_score(scr, pair, **kw)
+    trials = api.host_move_trials(pair[side], move, degen, primer_min, primer_max)
+    best_w, best = (0, 0), EMPTY_SCORE
+    if not trials:
+        return best_w, best
+    ok = scr.is_valid(trials, check_homo_dimer=False, salt=salt, primer_strand=primer_strand, tm_min=tm_min, tm_max=tm_max,
+                      max_hairpin=max_hairpin, max_dimer=0.0)
+    live = [t for t, r in zip(trials, ok) if r["valid"]]
+    if not live:
+        return best_w, best
+    tcov, _, _ = scr.move_coverage(pair, side, live, target_threshold, search_multiplier, amp_min, amp_max, use_taq_mama,
+                                   which=api.TARGET)
+    if have_background:
+        bcov, _, _ = scr.move_coverage(pair, side, live, bg_threshold, bg_multiplier, bg_amp_min, bg_amp_max, use_taq_mama,
+                                       which=api.BACKGROUND)
+    else:
+        bcov = np.zeros(len(live), np.float32)
+    for t, tc, bc in zip(live, tcov, bcov):
+        bound = np.float32(np.float32(tc) + np.float32(score_threshold[1])) - np.float32(score_threshold[0])   # optimize_pcr.cpp:95-97
+        if bound <= 0.0:                                                                                        # :102-109
+            continue
+        trial = (np.float32(tc), np.float32(bc), np.float32(0.0))
+        if score_gt(trial, best):
+            best, best_w = trial, t
+    return best_w, best

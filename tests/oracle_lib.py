@@ -254,6 +254,37 @@ class Reference(_Lib):
         return os.path.exists(cls.path)
 
 
+class MoveOptions(C.Structure):
+    _fields_ = [("degen", C.c_int), ("primer_min", C.c_int), ("primer_max", C.c_int),
+                ("salt", C.c_float), ("primer_strand", C.c_float), ("tm_min", C.c_float), ("tm_max", C.c_float),
+                ("max_hairpin", C.c_float), ("bg_threshold", C.c_float), ("bg_multiplier", C.c_float),
+                ("bg_amp_min", C.c_int), ("bg_amp_max", C.c_int)]
+
+
+DEFAULT_MOVE_OPTIONS = dict(degen=1, primer_min=18, primer_max=25, salt=0.05, primer_strand=9.0e-7, tm_min=50.0,
+                            tm_max=70.0, max_hairpin=40.0, bg_threshold=0.8, bg_multiplier=0.9, bg_amp_min=0,
+                            bg_amp_max=2000)
+
+
+def optimization_move(lib, target_session, background_session, pair, move, side, **mo):
+    """One complete local-search move (optimize_pcr.cpp) -> ((w0, w1), (tc, bc, overlap), (base tc, base bc))."""
+    o = dict(DEFAULT_MOVE_OPTIONS)
+    o.update(mo)
+    opts = MoveOptions(**o)
+    a = pairs_array([pair])
+    w = np.zeros(2, dtype=np.uint64)
+    sc = np.zeros(3, dtype=np.float32)
+    base = np.zeros(2, dtype=np.float32)
+    fn = getattr(lib.lib, lib.prefix + "optimization_move")
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(MoveOptions), C.c_void_p, C.c_void_p,
+                   C.c_void_p]
+    rc = fn(target_session.h, background_session.h if background_session is not None else None, a.ctypes.data, int(move),
+            int(side), C.byref(opts), w.ctypes.data, sc.ctypes.data, base.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(target_session.f("session_error")(target_session.h))
+    return (int(w[0]), int(w[1])), tuple(float(x) for x in sc), tuple(float(x) for x in base)
+
+
 def pairs_array(pairs):
     """pairs: list of (F, R) with F, R = (u64, u64) -> contiguous uint64 [n, 4]."""
     a = np.zeros((len(pairs), 4), dtype=np.uint64)

@@ -82,3 +82,29 @@ def test_thermo_golden():
         for c, o in zip(g["dimers"], ok):
             assert int(o) == c["compatible"][md]
     d.close()
+
+
+@pytest.mark.parametrize("ci", range(3))
+def test_moves_golden(ci):
+    """Complete local-search moves (tests/golden/moves.json: the reference's own optimization_move()) through
+    pcramp_amd.moves: host trial generation, device is_valid, device move coverage, Score logic."""
+    from pcramp_amd import moves
+    with open(os.path.join(G, "moves.json")) as f:
+        c = json.load(f)["cases"][ci]
+    o, mo = c["options"], c["move_options"]
+    d = api.Screener(0)
+    try:
+        d.load_texts(c["seqs"], c["weights"], which=api.TARGET)
+        d.load_texts(c["backgrounds"], [1.0] * len(c["backgrounds"]), which=api.BACKGROUND)
+        pairs = [((int(p[0], 16), int(p[1], 16)), (int(p[2], 16), int(p[3], 16))) for p in c["pairs"]]
+        thr = float(np.float32(o["target_threshold"]) * np.float32(o["search_multiplier"]))
+        d.select_words(pairs, thr, o["min_primer"], which=api.TARGET)
+        d.select_words(pairs, float(np.float32(c["bg_select_threshold"])), c["bg_min_len"], which=api.BACKGROUND)
+        for pi, side, move, wh, sc, base in c["moves"]:
+            w, s = moves.optimization_move(d, pairs[pi], move, side, target_threshold=o["target_threshold"],
+                                           search_multiplier=o["search_multiplier"], amp_min=o["amp_min"], amp_max=o["amp_max"],
+                                           use_taq_mama=bool(o["use_taq_mama"]), **mo)
+            assert w == (int(wh[0], 16), int(wh[1], 16)), (pi, side, move)
+            assert tuple(float(x) for x in s) == tuple(float(np.float32(x)) for x in sc), (pi, side, move)
+    finally:
+        d.close()

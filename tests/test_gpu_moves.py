@@ -76,3 +76,60 @@ def test_move_coverage_of_the_base_word_is_compute_coverage(oracle):
                 assert c[0] == cov[k]
     finally:
         d.close()
+
+
+@pytest.mark.parametrize("case", [dict(), dict(degen=16), dict(target_threshold=0.9, degen=4, use_taq_mama=1),
+                                  dict(degen=8, tm_min=-100.0, tm_max=200.0, max_hairpin=500.0)])
+def test_optimization_move_matches_oracle(oracle, case):
+    """The six local-search moves for both oligos: host trial generation + device is_valid + device coverage +
+    Score logic (pcramp_amd.moves) return the same trial word and Score as the oracle (itself pinned to the
+    reference's own optimization_move() in test_oracle_vs_reference)."""
+    from oracle_lib import optimization_move as oracle_move
+    from pcramp_amd import moves
+    from testdata import mutate, rand_seq
+    case = dict(case)
+    sess = {k: case.pop(k) for k in ("target_threshold", "use_taq_mama") if k in case}
+    o = dict(target_threshold=1.0, search_multiplier=0.9, amp_min=80, amp_max=200, use_taq_mama=0,
+             pack_max_degen=256, pack_min_gc=0.0, pack_max_gc=1.0, min_primer=18, optimize_5=0, optimize_3=0)
+    o.update(sess)
+    rng = random.Random(313 + len(case))
+    seqs = family_targets(rng, 3, 8, 600, div=0.06)
+    bgs = [mutate(rng, s, 0.12) for s in seqs[::4]] + [rand_seq(rng, 500) for _ in range(3)]
+    pairs_txt = []
+    while len(pairs_txt) < 6:
+        p = sample_pair(rng, rng.choice(seqs))
+        if p:
+            pairs_txt.append(p)
+    deg = []
+    for f, r in pairs_txt[:3]:
+        f = list(f); f[rng.randrange(3, len(f) - 3)] = rng.choice("RYKM"); deg.append(("".join(f), r))
+    pairs = [(oracle.centered_word(f), oracle.centered_word(r)) for f, r in pairs_txt + deg]
+    tw = [1.0 + 0.3 * (i % 4) for i in range(len(seqs))]
+    to, bo = oracle.session(**o), oracle.session(**o)
+    for s, w in zip(seqs, tw):
+        to.add_target(s, w)
+    for s in bgs:
+        bo.add_target(s, 1.0)
+    to.select(pairs)
+    bthr = float(np.float32(0.8) * np.float32(0.9))
+    bo.select(pairs, threshold=bthr, min_len_override=16)
+    d = api.Screener(0)
+    try:
+        d.load_texts(seqs, tw, which=api.TARGET)
+        d.load_texts(bgs, [1.0] * len(bgs), which=api.BACKGROUND)
+        thr = float(np.float32(o["target_threshold"]) * np.float32(o["search_multiplier"]))
+        d.select_words(pairs, thr, 18, which=api.TARGET)
+        d.select_words(pairs, bthr, 16, which=api.BACKGROUND)
+        n_nonempty = 0
+        for p in pairs:
+            for side in (0, 1):
+                for move in range(6):
+                    wo, so_, base = oracle_move(oracle, to, bo, p, move, side, **case)
+                    wd, sd = moves.optimization_move(d, p, move, side, target_threshold=o["target_threshold"],
+                                                     use_taq_mama=bool(o["use_taq_mama"]), **case)
+                    assert wd == wo, (move, side)
+                    assert tuple(float(x) for x in sd) == so_, (move, side)
+                    n_nonempty += wo != (0, 0)
+        assert n_nonempty > 10
+    finally:
+        d.close()

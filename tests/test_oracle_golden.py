@@ -89,3 +89,24 @@ def test_thermo(oracle):
         assert oracle.max_dimer_tm(p) == np.float32(c["max_dimer_tm"])
         for md, v in c["compatible"].items():
             assert oracle.multiplex_compatible(p, q, max_dimer=float(md)) == v
+
+
+@pytest.mark.parametrize("ci", range(3))
+def test_moves(oracle, ci):
+    """Complete local-search moves (optimize_pcr.cpp via optimization_move()): the reference's returned trial
+    word and Score for six moves x both oligos x five assays."""
+    from oracle_lib import optimization_move
+    c = load("moves")["cases"][ci]
+    ts, bs = oracle.session(**c["options"]), oracle.session(**c["options"])
+    for q, wt in zip(c["seqs"], c["weights"]):
+        ts.add_target(q, wt)
+    for q in c["backgrounds"]:
+        bs.add_target(q, 1.0)
+    pairs = [((int(p[0], 16), int(p[1], 16)), (int(p[2], 16), int(p[3], 16))) for p in c["pairs"]]
+    ts.select(pairs)
+    bs.select(pairs, threshold=c["bg_select_threshold"], min_len_override=c["bg_min_len"])
+    for pi, side, move, wh, sc, base in c["moves"]:
+        got = optimization_move(oracle, ts, bs, pairs[pi], move, side, **c["move_options"])
+        assert got[0] == (int(wh[0], 16), int(wh[1], 16))
+        assert got[1] == tuple(float(np.float32(x)) for x in sc)
+        assert got[2] == tuple(float(np.float32(x)) for x in base)

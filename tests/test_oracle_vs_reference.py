@@ -379,3 +379,42 @@ def test_move_coverage(oracle, reference, opts):
             n_checked += len(var)
             n_nonzero += int(np.count_nonzero(co))
     assert n_checked > 500 and n_nonzero > 50
+
+
+@pytest.mark.parametrize("case", [dict(), dict(degen=16), dict(target_threshold=0.9, degen=4, use_taq_mama=1),
+                                  dict(degen=8, tm_min=-100.0, tm_max=200.0, max_hairpin=500.0)])
+def test_optimization_move(oracle, reference, case):
+    """Every local-search move of optimize_pcr.cpp for both oligos, run by the reference's own
+    optimization_move() and by the oracle: returned trial word and Score identical (targets and backgrounds,
+    non-multiplex)."""
+    from oracle_lib import optimization_move
+    from testdata import mutate
+    case = dict(case)
+    sess = {k: case.pop(k) for k in ("target_threshold", "use_taq_mama") if k in case}
+    rng = random.Random(313 + len(case))
+    seqs = family_targets(rng, 3, 8, 600, div=0.06)
+    bgs = [mutate(rng, s, 0.12) for s in seqs[::4]] + [rand_seq(rng, 500) for _ in range(3)]
+    pairs_txt = []
+    while len(pairs_txt) < 6:
+        p = sample_pair(rng, rng.choice(seqs))
+        if p:
+            pairs_txt.append(p)
+    # some degenerate starting oligos so that -degeneracy has trials
+    deg = []
+    for f, r in pairs_txt[:3]:
+        f = list(f); f[rng.randrange(3, len(f) - 3)] = rng.choice("RYKM"); deg.append(("".join(f), r))
+    pairs = [(reference.centered_word(f), reference.centered_word(r)) for f, r in pairs_txt + deg]
+    to, tr = _sessions(oracle, reference, seqs, [1.0 + 0.3 * (i % 4) for i in range(len(seqs))], **sess)
+    bo, br = _sessions(oracle, reference, bgs, None, **sess)
+    assert to.select(pairs) == tr.select(pairs)
+    bthr = float(np.float32(0.8) * np.float32(0.9))
+    assert bo.select(pairs, threshold=bthr, min_len_override=16) == br.select(pairs, threshold=bthr, min_len_override=16)
+    n_nonempty = 0
+    for p in pairs:
+        for side in (0, 1):
+            for move in range(6):
+                ro = optimization_move(oracle, to, bo, p, move, side, **case)
+                rr = optimization_move(reference, tr, br, p, move, side, **case)
+                assert ro == rr, (move, side, ro, rr)
+                n_nonempty += ro[0] != (0, 0)
+    assert n_nonempty > 10
