@@ -203,7 +203,7 @@ def thermo_golden(ref):
 def moves_golden(ref):
     """The six local-search moves of optimize_pcr.cpp run by the reference's optimization_move() for both
     oligos of a few assays (targets + backgrounds, non-multiplex): returned trial word and Score."""
-    from oracle_lib import optimization_move, DEFAULT_MOVE_OPTIONS
+    from oracle_lib import optimization_move, optimize, DEFAULT_MOVE_OPTIONS
     from testdata import mutate
     cases = []
     for ci, case in enumerate([dict(), dict(degen=16), dict(target_threshold=0.9, degen=4, use_taq_mama=1)]):
@@ -222,6 +222,11 @@ def moves_golden(ref):
         f = list(f); f[rng.randrange(3, len(f) - 3)] = rng.choice("RYKM")
         pairs_txt.append(("".join(f), r))
         pairs = [(ref.centered_word(a), ref.centered_word(b)) for a, b in pairs_txt]
+        # two damaged assays: the full optimize() loop has something to repair
+        for a0, b0 in pairs_txt[1:3]:
+            pairs_txt.append((mutate(rng, a0, 0.1), mutate(rng, b0, 0.1)))
+        pairs = [(ref.centered_word(a), ref.centered_word(b)) for a, b in pairs_txt]
+        sess = dict(sess, optimize_5=1, optimize_3=1)
         ts, bs = ref.session(**sess), ref.session(**sess)
         for q, wt in zip(seqs, weights):
             ts.add_target(q, wt)
@@ -229,6 +234,10 @@ def moves_golden(ref):
             bs.add_target(q, 1.0)
         ts.select(pairs)
         bs.select(pairs, threshold=0.8 * 0.9, min_len_override=16)
+        opt_out = []
+        for pi, p in enumerate(pairs):
+            bp, sc = optimize(ref, ts, bs, p, **case)
+            opt_out.append([pi, hexw(bp[0]) + hexw(bp[1]), list(sc)])
         out = []
         for pi, p in enumerate(pairs):
             for side in (0, 1):
@@ -238,7 +247,7 @@ def moves_golden(ref):
         mo = dict(DEFAULT_MOVE_OPTIONS); mo.update(case)
         cases.append({"options": ts.opts, "move_options": mo, "seqs": seqs, "weights": weights, "backgrounds": bgs,
                       "bg_select_threshold": 0.8 * 0.9, "bg_min_len": 16,
-                      "pairs": [hexw(a) + hexw(b) for a, b in pairs], "moves": out})
+                      "pairs": [hexw(a) + hexw(b) for a, b in pairs], "moves": out, "optimize": opt_out})
     return {"cases": cases}
 
 

@@ -682,7 +682,94 @@ struct ScoreO {                                                                 
 	float tc = -1.0e6f, bc = 1.0e6f, ov = 0.0f;
 	float accuracy() const { return tc - bc; }
 	bool gt(const ScoreO &r) const { return (accuracy() == r.accuracy()) ? (ov > r.ov) : (accuracy() > r.accuracy()); }
+	bool lt(const ScoreO &r) const { return (accuracy() == r.accuracy()) ? (ov < r.ov) : (accuracy() < r.accuracy()); }
+	bool eq(const ScoreO &r) const { return accuracy() == r.accuracy() && ov == r.ov; }
 };
+}
+
+namespace {
+// Candidates, identity tables and score of the base assay (optimize.cpp:61-79)
+struct MoveState {
+	std::vector<Amplicon> tamp, bamp;
+	std::map<uint32_t, float> tfi, tri, bfi, bri;
+	ScoreO base;
+};
+
+void move_state(MoveState &m, orc_session *t, orc_session *b, const W &F, const W &R, const orc_move_options *mo)
+{
+	const bool taq = t->opt.use_taq_mama != 0;
+	collect_candidates(m.tamp, m.tfi, m.tri, F, R, *t, t->opt.target_threshold*t->opt.search_multiplier, t->opt.amp_min, t->opt.amp_max);
+	m.bamp.clear(); m.bfi.clear(); m.bri.clear();
+	if(b && !b->keys.empty())                                                         // assay.h:411-421
+		collect_candidates(m.bamp, m.bfi, m.bri, F, R, *b, mo->bg_threshold*mo->bg_multiplier, mo->bg_amp_min, mo->bg_amp_max);
+	update_identity(m.tfi, F, t->keys, taq); update_identity(m.tri, R, t->keys, taq);
+	if(b){ update_identity(m.bfi, F, b->keys, taq); update_identity(m.bri, R, b->keys, taq); }
+	m.base.tc = coverage_of(m.tamp, m.tfi, m.tri, t->opt.target_threshold);
+	m.base.bc = coverage_of(m.bamp, m.bfi, m.bri, mo->bg_threshold);
+	m.base.ov = 0.0f;
+}
+
+// One move function of optimize_pcr.cpp for oligo `side` of (F, R); `thr` = m_score_threshold
+void move_eval(MoveState &m, orc_session *t, orc_session *b, const W &F, const W &R, int move, int side,
+	const orc_move_options *mo, const ScoreO &thr, W &best_w, ScoreO &best)
+{
+	const bool taq = t->opt.use_taq_mama != 0;
+	const W cur = side == 0 ? F : R;
+	// the trial words, in the reference's order, after its cheap gates (before is_valid)
+	std::vector<W> trials;
+	const int len = (int)cur.size();
+	switch(move){
+		case 0:                                                                       // increase_degeneracy, optimize_pcr.cpp:17-19,54-76
+			if(cur.degeneracy() >= mo->degen) break;
+			for(int i = cur.start();i <= cur.stop();++i){
+				for(unsigned bb = 1;bb <= 8;bb <<= 1){
+					if(cur.get(i) & bb) continue;
+					W w = cur; w.set(cur.get(i) | bb, i);
+					if(w.degeneracy() > mo->degen) continue;
+					trials.push_back(w);
+				}
+			}
+			break;
+		case 1:                                                                       // decrease_degeneracy, :232-247
+			for(int i = cur.start();i <= cur.stop();++i){
+				const unsigned c = cur.get(i);
+				for(unsigned bb = 1;bb <= 8;bb <<= 1){
+					const unsigned d = c & ~bb;
+					if(!d || d == c) continue;
+					W w = cur; w.set(d, i); trials.push_back(w);
+				}
+			}
+			break;
+		case 2: if(len != mo->primer_min){ W w = cur; if(w.start() < 32) w.set(0, w.start()); trials.push_back(w); } break;   // trim5 :391-399, word.h:355
+		case 3: if(len != mo->primer_min){ W w = cur; if(w.stop() >= 0) w.set(0, w.stop()); trials.push_back(w); } break;    // trim3, word.h:364
+		case 4:                                                                       // grow5 :671-673,709-713, word.h:374
+			if(len == mo->primer_max) break;
+			for(unsigned bb = 1;bb <= 8;bb <<= 1){ W w = cur; const int i = w.start() - 1; if(i >= 0) w.set(bb, i); trials.push_back(w); }
+			break;
+		case 5:                                                                       // grow3, word.h:383
+			if(len == mo->primer_max) break;
+			for(unsigned bb = 1;bb <= 8;bb <<= 1){ W w = cur; const int i = w.stop() + 1; if(i < 32) w.set(bb, i); trials.push_back(w); }
+			break;
+		default: throw "unknown move";
+	}
+	best = ScoreO(); best_w.b[0] = best_w.b[1] = 0;
+	for(const W &w : trials){
+		const int ok = orc_is_valid(w.b, mo->salt, mo->primer_strand, mo->tm_min, mo->tm_max, mo->max_hairpin, 0.0f, 0);
+		if(ok < 0) throw "is_valid failed";
+		if(!ok) continue;
+		ScoreO tr;
+		update_identity(side == 0 ? m.tfi : m.tri, w, t->keys, taq);
+		tr.tc = coverage_of(m.tamp, m.tfi, m.tri, t->opt.target_threshold);
+		const float bound = tr.tc + thr.bc - thr.tc;                                 // :95-97
+		if(bound <= 0.0f) continue;                                                   // :102-109 (non-multiplex)
+		if(b) update_identity(side == 0 ? m.bfi : m.bri, w, b->keys, taq);
+		tr.bc = coverage_of(m.bamp, m.bfi, m.bri, mo->bg_threshold);
+		if(tr.gt(best)){ best = tr; best_w = w; }
+	}
+	// the move functions restore the identity tables of the unmodified oligo before returning
+	update_identity(side == 0 ? m.tfi : m.tri, cur, t->keys, taq);
+	if(b) update_identity(side == 0 ? m.bfi : m.bri, cur, b->keys, taq);
+}
 }
 
 int orc_optimization_move(orc_session *t, orc_session *b, const uint64_t pair[4], int move, int side,
@@ -690,73 +777,60 @@ int orc_optimization_move(orc_session *t, orc_session *b, const uint64_t pair[4]
 {
 	try{
 		const W F = load_word(pair), R = load_word(pair + 2);
-		const bool taq = t->opt.use_taq_mama != 0;
-		// optimize.cpp:61-79: candidates and identity tables of the base assay, base score
-		std::vector<Amplicon> tamp, bamp;
-		std::map<uint32_t, float> tfi, tri, bfi, bri;
-		collect_candidates(tamp, tfi, tri, F, R, *t, t->opt.target_threshold*t->opt.search_multiplier, t->opt.amp_min, t->opt.amp_max);
-		if(b && !b->keys.empty())                                                     // assay.h:411-421
-			collect_candidates(bamp, bfi, bri, F, R, *b, mo->bg_threshold*mo->bg_multiplier, mo->bg_amp_min, mo->bg_amp_max);
-		update_identity(tfi, F, t->keys, taq); update_identity(tri, R, t->keys, taq);
-		if(b){ update_identity(bfi, F, b->keys, taq); update_identity(bri, R, b->keys, taq); }
-		ScoreO base;
-		base.tc = coverage_of(tamp, tfi, tri, t->opt.target_threshold);
-		base.bc = coverage_of(bamp, bfi, bri, mo->bg_threshold);
-		if(base_score_out){ base_score_out[0] = base.tc; base_score_out[1] = base.bc; }
-		const W cur = side == 0 ? F : R;
-		// the trial words, in the reference's order, after its cheap gates (before is_valid)
-		std::vector<W> trials;
-		const int len = (int)cur.size();
-		switch(move){
-			case 0:                                                                   // increase_degeneracy, optimize_pcr.cpp:17-19,54-76
-				if(cur.degeneracy() >= mo->degen) break;
-				for(int i = cur.start();i <= cur.stop();++i){
-					for(unsigned bb = 1;bb <= 8;bb <<= 1){
-						if(cur.get(i) & bb) continue;
-						W w = cur; w.set(cur.get(i) | bb, i);
-						if(w.degeneracy() > mo->degen) continue;
-						trials.push_back(w);
-					}
-				}
-				break;
-			case 1:                                                                   // decrease_degeneracy, :232-247
-				for(int i = cur.start();i <= cur.stop();++i){
-					const unsigned c = cur.get(i);
-					for(unsigned bb = 1;bb <= 8;bb <<= 1){
-						const unsigned d = c & ~bb;
-						if(!d || d == c) continue;
-						W w = cur; w.set(d, i); trials.push_back(w);
-					}
-				}
-				break;
-			case 2: if(len != mo->primer_min){ W w = cur; if(w.start() < 32) w.set(0, w.start()); trials.push_back(w); } break;   // trim5 :391-399, word.h:355
-			case 3: if(len != mo->primer_min){ W w = cur; if(w.stop() >= 0) w.set(0, w.stop()); trials.push_back(w); } break;    // trim3, word.h:364
-			case 4:                                                                   // grow5 :671-673,709-713, word.h:374
-				if(len == mo->primer_max) break;
-				for(unsigned bb = 1;bb <= 8;bb <<= 1){ W w = cur; const int i = w.start() - 1; if(i >= 0) w.set(bb, i); trials.push_back(w); }
-				break;
-			case 5:                                                                   // grow3, word.h:383
-				if(len == mo->primer_max) break;
-				for(unsigned bb = 1;bb <= 8;bb <<= 1){ W w = cur; const int i = w.stop() + 1; if(i < 32) w.set(bb, i); trials.push_back(w); }
-				break;
-			default: throw "unknown move";
-		}
-		ScoreO best; W best_w; best_w.b[0] = best_w.b[1] = 0;
-		for(const W &w : trials){
-			const int ok = orc_is_valid(w.b, mo->salt, mo->primer_strand, mo->tm_min, mo->tm_max, mo->max_hairpin, 0.0f, 0);
-			if(ok < 0) throw "is_valid failed";
-			if(!ok) continue;
-			ScoreO tr;                                                                // the reference reuses one trial_score: fields not set below keep defaults only for the first trial;
-			update_identity(side == 0 ? tfi : tri, w, t->keys, taq);                  // a skipped trial never reaches the comparison, so it does not matter
-			tr.tc = coverage_of(tamp, tfi, tri, t->opt.target_threshold);
-			const float bound = tr.tc + base.bc - base.tc;                           // :95-97 (m_score_threshold = the base score)
-			if(bound <= 0.0f) continue;                                               // :102-109 (non-multiplex)
-			if(b) update_identity(side == 0 ? bfi : bri, w, b->keys, taq);
-			tr.bc = coverage_of(bamp, bfi, bri, mo->bg_threshold);
-			if(tr.gt(best)){ best = tr; best_w = w; }
-		}
+		MoveState m;
+		move_state(m, t, b, F, R, mo);
+		if(base_score_out){ base_score_out[0] = m.base.tc; base_score_out[1] = m.base.bc; }
+		W best_w; ScoreO best;
+		move_eval(m, t, b, F, R, move, side, mo, m.base, best_w, best);
 		out_word[0] = best_w.b[0]; out_word[1] = best_w.b[1];
 		out_score[0] = best.tc; out_score[1] = best.bc; out_score[2] = best.ov;
+		return 0;
+	}
+	catch(const char *e){ t->err = e; return -1; }
+}
+
+// optimize() (optimize.cpp:14-207), non-multiplex: greedy local search over `moves` for both oligos.
+// pair_inout receives the best assay; returns its score.
+int orc_optimize(orc_session *t, orc_session *b, uint64_t pair_inout[4], const int *moves, int n_moves,
+	const orc_move_options *mo, float out_score[3], int *iterations_out)
+{
+	try{
+		W bestF = load_word(pair_inout), bestR = load_word(pair_inout + 2);
+		W aF = bestF, aR = bestR;
+		ScoreO best_score, approx_score;
+		std::set<std::pair<W, W> > previous;
+		previous.insert(std::make_pair(bestF, bestR));
+		int iteration = 0;
+		while(true){
+			bool improved = false;
+			++iteration;
+			MoveState m;
+			move_state(m, t, b, aF, aR, mo);                                          // :61-79
+			approx_score = m.base;
+			if(approx_score.lt(best_score)) break;                                    // :99-105
+			best_score = approx_score; bestF = aF; bestR = aR;
+			W local_seq; local_seq.b[0] = local_seq.b[1] = 0;
+			int local_oligo = -1;
+			ScoreO local_score = approx_score;
+			for(int side = 0;side < 2;++side){                                        // :120-141
+				for(int k = 0;k < n_moves;++k){
+					W w; ScoreO sc;
+					move_eval(m, t, b, aF, aR, moves[k], side, mo, local_score, w, sc);
+					if(sc.gt(local_score) || (sc.eq(local_score) && w.degeneracy() < local_seq.degeneracy())){
+						local_score = sc; local_seq = w; local_oligo = side; improved = true;
+					}
+				}
+			}
+			if(!improved) break;
+			approx_score = local_score;
+			local_seq.center();                                                       // :152
+			if(local_oligo == 0) aF = local_seq; else aR = local_seq;
+			if(previous.find(std::make_pair(aF, aR)) != previous.end()) break;        // :196-202
+			previous.insert(std::make_pair(aF, aR));
+		}
+		pair_inout[0] = bestF.b[0]; pair_inout[1] = bestF.b[1]; pair_inout[2] = bestR.b[0]; pair_inout[3] = bestR.b[1];
+		out_score[0] = best_score.tc; out_score[1] = best_score.bc; out_score[2] = best_score.ov;
+		if(iterations_out) *iterations_out = iteration;
 		return 0;
 	}
 	catch(const char *e){ t->err = e; return -1; }

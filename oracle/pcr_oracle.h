@@ -99,6 +99,11 @@ typedef struct {
 int orc_optimization_move(orc_session *t, orc_session *b, const uint64_t pair[4], int move, int side,
 	const orc_move_options *mo, uint64_t out_word[2], float out_score[3], float base_score_out[2]);
 
+// optimize() (optimize.cpp:14-207), non-multiplex: the greedy local search around the moves; moves[] in the
+// order of main.cpp:82-95.  pair_inout: the assay, replaced by the best one found.
+int orc_optimize(orc_session *t, orc_session *b, uint64_t pair_inout[4], const int *moves, int n_moves,
+	const orc_move_options *mo, float out_score[3], int *iterations_out);
+
 float orc_weighted_coverage(orc_session *s, const unsigned char *bits);
 
 // ---- Smith-Waterman (SO::SeqOverlap, SmithWaterman + nucleic-acid mode; seq_overlap.cpp:347-609)

@@ -25,6 +25,7 @@
 #include <cstdint>
 #include <cstring>
 #include <string>
+#include <sstream>
 #include <vector>
 #include <deque>
 
@@ -415,6 +416,46 @@ int ref_optimization_move(RefSession *t, RefSession *b, const uint64_t pair[4], 
 		r.first.mpi_pack(buf);
 		memcpy(out_word, buf, 16);
 		out_score[0] = r.second.target_coverage; out_score[1] = r.second.background_coverage; out_score[2] = r.second.oligo_overlap;
+		return 0;
+	}
+	catch(const char *e){ t->last_error = e; return -1; }
+	catch(...){ t->last_error = "unknown"; return -2; }
+}
+
+// optimize() itself (optimize.cpp:14-207), non-multiplex.
+int ref_optimize(RefSession *t, RefSession *b, uint64_t pair_inout[4], const int *moves, int n_moves,
+	const RefMoveOptions *mo, float out_score[3], int *iterations_out)
+{
+	try{
+		Options opt = t->opt;
+		opt.degen = mo->degen;
+		opt.primer_range = make_pair(mo->primer_min, mo->primer_max);
+		opt.salt = mo->salt; opt.primer_strand = mo->primer_strand;
+		opt.primer_tm_range = make_pair(mo->tm_min, mo->tm_max);
+		opt.max_hairpin = mo->max_hairpin;
+		opt.background_threshold = mo->bg_threshold;
+		opt.background_search_multiplier = mo->bg_multiplier;
+		opt.background_amplicon_range = make_pair(mo->bg_amp_min, mo->bg_amp_max);
+		opt.use_multiplex = false;
+		opt.output_filter = Options::SILENT;
+		const vector<Word> no_keys;
+		const MULTIMAP<Word, WordMatch> no_db;
+		const deque<Sequence> no_seq;
+		const Move mv[6] = { IncreaseDegeneracy, DecreaseDegeneracy, Trim5, Trim3, Grow5, Grow3 };
+		vector<Move> ml;
+		for(int i = 0;i < n_moves;++i){ if(moves[i] < 0 || moves[i] > 5) throw "unknown move"; ml.push_back(mv[moves[i]]); }
+		PCR p;
+		p.oligo( FORWARD, word_from(pair_inout) );
+		p.oligo( REVERSE, word_from(pair_inout + 2) );
+		const deque<PCR> pool;
+		std::ostringstream sink;
+		const Score sc = optimize(p, ml, t->target_keys, t->target_db, t->target_seq,
+			b ? b->target_keys : no_keys, b ? b->target_db : no_db, b ? b->target_seq : no_seq,
+			no_keys, no_db, no_seq, pool, opt, sink);
+		words_of(p.oligo(FORWARD), pair_inout);
+		words_of(p.oligo(REVERSE), pair_inout + 2);
+		out_score[0] = sc.target_coverage; out_score[1] = sc.background_coverage; out_score[2] = sc.oligo_overlap;
+		if(iterations_out) *iterations_out = -1;
 		return 0;
 	}
 	catch(const char *e){ t->last_error = e; return -1; }

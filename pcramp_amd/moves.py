@@ -10,6 +10,7 @@ optimize() is called inside main.cpp's per-iteration DB build.
 import numpy as np
 
 from . import api
+from . import words as W
 
 INCREASE_DEGENERACY, DECREASE_DEGENERACY, TRIM5, TRIM3, GROW5, GROW3 = range(6)
 
@@ -77,3 +78,54 @@ def optimization_move(scr, pair, move, side, score_threshold=None, degen=1, prim
         if score_gt(trial, best):
             best, best_w = trial, t
     return best_w, best
+
+
+def score_lt(a, b):
+    """Score::operator< (pcramp.h:181-188)."""
+    if _accuracy(a) == _accuracy(b):
+        return np.float32(a[2]) < np.float32(b[2])
+    return _accuracy(a) < _accuracy(b)
+
+
+def score_eq(a, b):
+    """Score::operator== (pcramp.h:199-203)."""
+    return _accuracy(a) == _accuracy(b) and np.float32(a[2]) == np.float32(b[2])
+
+
+DEFAULT_MOVES = (INCREASE_DEGENERACY, DECREASE_DEGENERACY, TRIM5, GROW5, TRIM3, GROW3)      # main.cpp:82-95
+
+
+def optimize(scr, pair, move_list=DEFAULT_MOVES, **opts):
+    """optimize() (optimize.cpp:14-207), non-multiplex: greedy local search over both oligos.
+
+    Per iteration: score of the current assay (collect + update + compute coverage, :61-79), every move of
+    every oligo against the running best (`local_score` doubles as the moves' score threshold, :126-130; ties
+    go to the lower degeneracy, :133-135), the winner re-centred and installed (:152-154); stops when nothing
+    improves, when the score drops, or when an assay repeats (:196-202).  -> (best pair, Score)."""
+    cov_kw = {k: opts[k] for k in ("target_threshold", "search_multiplier", "amp_min", "amp_max", "use_taq_mama",
+                                   "bg_threshold", "bg_multiplier", "bg_amp_min", "bg_amp_max", "have_background") if k in opts}
+    best = (tuple(int(x) for x in pair[0]), tuple(int(x) for x in pair[1]))
+    approx = best
+    best_score = EMPTY_SCORE
+    previous = {approx}
+    while True:
+        tc, bc = base_score(scr, approx, **cov_kw)
+        approx_score = (tc, bc, np.float32(0.0))
+        if score_lt(approx_score, best_score):
+            break
+        best_score, best = approx_score, approx
+        local_seq, local_oligo, local_score, improved = (0, 0), None, approx_score, False
+        for side in (0, 1):
+            for mv in move_list:
+                w, sc = optimization_move(scr, approx, mv, side, score_threshold=local_score, **opts)
+                if score_gt(sc, local_score) or (score_eq(sc, local_score) and W.word_degeneracy(w) < W.word_degeneracy(local_seq)):
+                    local_score, local_seq, local_oligo, improved = sc, w, side, True
+        if not improved:
+            break
+        approx_score = local_score
+        centred = W.center_word(local_seq)
+        approx = (centred, approx[1]) if local_oligo == 0 else (approx[0], centred)
+        if approx in previous:
+            break
+        previous.add(approx)
+    return best, best_score

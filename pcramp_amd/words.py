@@ -75,6 +75,32 @@ def centered_word(codes):
     return word_from_slots(slots)
 
 
+def center_word(word):
+    """Word::center() (word.h:392-418): delta = ((32 - stop) - start)/2 truncated toward zero; shift right by
+    delta if positive, left by -delta otherwise."""
+    s = [int(v) for v in slots_from_word(word)]
+    occ = [k for k in range(32) if s[k]]
+    if not occ:
+        return (int(word[0]), int(word[1]))
+    left, right = occ[0], 32 - occ[-1]
+    delta = int((right - left) / 2)            # C++ int division truncates toward zero
+    out = [0] * 32
+    for k in occ:
+        if 0 <= k + delta < 32:
+            out[k + delta] = s[k]
+    return word_from_slots(out)
+
+
+def word_degeneracy(word):
+    """Word::degeneracy() (word.h:97-138): product of the slot multiplicities (1.0 for the empty word)."""
+    d = 1.0
+    for v in slots_from_word(word):
+        n = bin(int(v)).count("1")
+        if n:
+            d *= n
+    return d
+
+
 def word_text(word):
     s = slots_from_word(word)
     nz = np.nonzero(s)[0]

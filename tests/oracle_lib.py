@@ -285,6 +285,26 @@ def optimization_move(lib, target_session, background_session, pair, move, side,
     return (int(w[0]), int(w[1])), tuple(float(x) for x in sc), tuple(float(x) for x in base)
 
 
+def optimize(lib, target_session, background_session, pair, moves=(0, 1, 2, 4, 3, 5), **mo):
+    """optimize() (optimize.cpp:14-207), non-multiplex; moves in main.cpp:82-95 order by default
+    -> (best pair, (tc, bc, overlap))."""
+    o = dict(DEFAULT_MOVE_OPTIONS)
+    o.update(mo)
+    opts = MoveOptions(**o)
+    a = pairs_array([pair]).copy()
+    mv = np.array(list(moves), dtype=np.int32)
+    sc = np.zeros(3, dtype=np.float32)
+    it = C.c_int(0)
+    fn = getattr(lib.lib, lib.prefix + "optimize")
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(MoveOptions), C.c_void_p, C.POINTER(C.c_int)]
+    rc = fn(target_session.h, background_session.h if background_session is not None else None, a.ctypes.data, mv.ctypes.data,
+            len(mv), C.byref(opts), sc.ctypes.data, C.byref(it))
+    if rc != 0:
+        raise RuntimeError(target_session.f("session_error")(target_session.h))
+    flat = a.reshape(-1)
+    return ((int(flat[0]), int(flat[1])), (int(flat[2]), int(flat[3]))), tuple(float(x) for x in sc)
+
+
 def pairs_array(pairs):
     """pairs: list of (F, R) with F, R = (u64, u64) -> contiguous uint64 [n, 4]."""
     a = np.zeros((len(pairs), 4), dtype=np.uint64)

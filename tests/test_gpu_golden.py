@@ -98,13 +98,19 @@ def test_moves_golden(ci):
         d.load_texts(c["backgrounds"], [1.0] * len(c["backgrounds"]), which=api.BACKGROUND)
         pairs = [((int(p[0], 16), int(p[1], 16)), (int(p[2], 16), int(p[3], 16))) for p in c["pairs"]]
         thr = float(np.float32(o["target_threshold"]) * np.float32(o["search_multiplier"]))
-        d.select_words(pairs, thr, o["min_primer"], which=api.TARGET)
-        d.select_words(pairs, float(np.float32(c["bg_select_threshold"])), c["bg_min_len"], which=api.BACKGROUND)
+        d.select_words(pairs, thr, o["min_primer"], o["optimize_5"], o["optimize_3"], which=api.TARGET)
+        d.select_words(pairs, float(np.float32(c["bg_select_threshold"])), c["bg_min_len"], o["optimize_5"], o["optimize_3"],
+                       which=api.BACKGROUND)
         for pi, side, move, wh, sc, base in c["moves"]:
             w, s = moves.optimization_move(d, pairs[pi], move, side, target_threshold=o["target_threshold"],
                                            search_multiplier=o["search_multiplier"], amp_min=o["amp_min"], amp_max=o["amp_max"],
                                            use_taq_mama=bool(o["use_taq_mama"]), **mo)
             assert w == (int(wh[0], 16), int(wh[1], 16)), (pi, side, move)
             assert tuple(float(x) for x in s) == tuple(float(np.float32(x)) for x in sc), (pi, side, move)
+        for pi, bp, sc in c["optimize"]:                               # the whole optimize() loop
+            got, s = moves.optimize(d, pairs[pi], target_threshold=o["target_threshold"], search_multiplier=o["search_multiplier"],
+                                    amp_min=o["amp_min"], amp_max=o["amp_max"], use_taq_mama=bool(o["use_taq_mama"]), **mo)
+            assert got == ((int(bp[0], 16), int(bp[1], 16)), (int(bp[2], 16), int(bp[3], 16))), pi
+            assert tuple(float(x) for x in s) == tuple(float(np.float32(x)) for x in sc), pi
     finally:
         d.close()

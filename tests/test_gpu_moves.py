@@ -133,3 +133,55 @@ def test_optimization_move_matches_oracle(oracle, case):
         assert n_nonempty > 10
     finally:
         d.close()
+
+
+@pytest.mark.parametrize("case", [dict(), dict(degen=16), dict(target_threshold=0.9, degen=4, use_taq_mama=1),
+                                  dict(degen=64, target_threshold=0.85, tm_min=40.0, tm_max=80.0)])
+def test_optimize_loop_matches_oracle(oracle, case):
+    """optimize() (the greedy local search) over the device primitives == the oracle's restatement (pinned to the
+    reference's optimize() in test_oracle_vs_reference): final assay and Score."""
+    from oracle_lib import optimize as oracle_optimize
+    from pcramp_amd import moves
+    from testdata import mutate, rand_seq
+    case = dict(case)
+    sess = {k: case.pop(k) for k in ("target_threshold", "use_taq_mama") if k in case}
+    o = dict(target_threshold=1.0, search_multiplier=0.9, amp_min=80, amp_max=200, use_taq_mama=0,
+             pack_max_degen=256, pack_min_gc=0.0, pack_max_gc=1.0, min_primer=18, optimize_5=1, optimize_3=1)
+    o.update(sess)
+    rng = random.Random(4242 + len(case))
+    seqs = family_targets(rng, 3, 8, 600, div=0.06)
+    bgs = [mutate(rng, s, 0.12) for s in seqs[::4]] + [rand_seq(rng, 500) for _ in range(3)]
+    pairs_txt = []
+    while len(pairs_txt) < 6:
+        p = sample_pair(rng, rng.choice(seqs))
+        if p:
+            pairs_txt.append(p)
+    for f, r in list(pairs_txt[:3]):
+        pairs_txt.append((mutate(rng, f, 0.1), mutate(rng, r, 0.1)))
+    pairs = [(oracle.centered_word(f), oracle.centered_word(r)) for f, r in pairs_txt]
+    tw = [1.0 + 0.3 * (i % 4) for i in range(len(seqs))]
+    to, bo = oracle.session(**o), oracle.session(**o)
+    for s, w in zip(seqs, tw):
+        to.add_target(s, w)
+    for s in bgs:
+        bo.add_target(s, 1.0)
+    to.select(pairs)
+    bthr = float(np.float32(0.8) * np.float32(0.9))
+    bo.select(pairs, threshold=bthr, min_len_override=16)
+    d = api.Screener(0)
+    try:
+        d.load_texts(seqs, tw, which=api.TARGET)
+        d.load_texts(bgs, [1.0] * len(bgs), which=api.BACKGROUND)
+        thr = float(np.float32(o["target_threshold"]) * np.float32(o["search_multiplier"]))
+        d.select_words(pairs, thr, 18, True, True, which=api.TARGET)
+        d.select_words(pairs, bthr, 16, True, True, which=api.BACKGROUND)
+        changed = 0
+        for p in pairs:
+            po, so_ = oracle_optimize(oracle, to, bo, p, **case)
+            pd, sd = moves.optimize(d, p, target_threshold=o["target_threshold"], use_taq_mama=bool(o["use_taq_mama"]), **case)
+            assert pd == po
+            assert tuple(float(x) for x in sd) == so_
+            changed += po != p
+        assert changed > 0
+    finally:
+        d.close()

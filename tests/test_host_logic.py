@@ -190,3 +190,18 @@ def test_seed_filter_declines_low_thresholds():
     assert s is not None and len(s) == 24 and all(q == 8 and off + 8 <= 32 for _, q, off in s)
     s = api.host_orientation_seeds(word, 20)                   # exact match required: one 8-gram
     assert s is not None and len(s) == 1
+
+
+def test_center_and_degeneracy_helpers_match_oracle(oracle):
+    """words.center_word / word_degeneracy (used by the optimize() loop) against the oracle's Word::center / degeneracy."""
+    rng = random.Random(9)
+    for _ in range(400):
+        n = rng.randint(1, 32)
+        start = rng.randint(0, 32 - n)
+        slots = [0] * 32
+        for k in range(start, start + n):
+            slots[k] = rng.choice([1, 2, 4, 8, 3, 5, 15, 7])
+        w = W.word_from_slots(slots)
+        assert W.center_word(w) == oracle.word_center(w)
+        assert W.word_degeneracy(w) == oracle.word_degeneracy(w)
+    assert W.center_word((0, 0)) == (0, 0)

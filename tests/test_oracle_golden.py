@@ -95,7 +95,7 @@ def test_thermo(oracle):
 def test_moves(oracle, ci):
     """Complete local-search moves (optimize_pcr.cpp via optimization_move()): the reference's returned trial
     word and Score for six moves x both oligos x five assays."""
-    from oracle_lib import optimization_move
+    from oracle_lib import optimization_move, optimize
     c = load("moves")["cases"][ci]
     ts, bs = oracle.session(**c["options"]), oracle.session(**c["options"])
     for q, wt in zip(c["seqs"], c["weights"]):
@@ -110,3 +110,7 @@ def test_moves(oracle, ci):
         assert got[0] == (int(wh[0], 16), int(wh[1], 16))
         assert got[1] == tuple(float(np.float32(x)) for x in sc)
         assert got[2] == tuple(float(np.float32(x)) for x in base)
+    for pi, bp, sc in c["optimize"]:                                   # the whole optimize() loop
+        got = optimize(oracle, ts, bs, pairs[pi], **c["move_options"])
+        assert got[0] == ((int(bp[0], 16), int(bp[1], 16)), (int(bp[2], 16), int(bp[3], 16)))
+        assert got[1] == tuple(float(np.float32(x)) for x in sc)

@@ -418,3 +418,39 @@ def test_optimization_move(oracle, reference, case):
                 assert ro == rr, (move, side, ro, rr)
                 n_nonempty += ro[0] != (0, 0)
     assert n_nonempty > 10
+
+
+@pytest.mark.parametrize("case", [dict(), dict(degen=16), dict(target_threshold=0.9, degen=4, use_taq_mama=1),
+                                  dict(degen=8, tm_min=-100.0, tm_max=200.0, max_hairpin=500.0),
+                                  dict(degen=64, target_threshold=0.85, tm_min=40.0, tm_max=80.0)])
+def test_optimize_loop(oracle, reference, case):
+    """The reference's optimize() (greedy local search, optimize.cpp:14-207) against the oracle's restatement:
+    final assay and Score identical, for assays sampled from the targets and for deliberately bad ones."""
+    from oracle_lib import optimize
+    from testdata import mutate
+    case = dict(case)
+    sess = {k: case.pop(k) for k in ("target_threshold", "use_taq_mama") if k in case}
+    rng = random.Random(4242 + len(case))
+    seqs = family_targets(rng, 3, 8, 600, div=0.06)
+    bgs = [mutate(rng, s, 0.12) for s in seqs[::4]] + [rand_seq(rng, 500) for _ in range(3)]
+    pairs_txt = []
+    while len(pairs_txt) < 8:
+        p = sample_pair(rng, rng.choice(seqs))
+        if p:
+            pairs_txt.append(p)
+    # primers with a few wrong bases: the search has something to repair
+    for f, r in list(pairs_txt[:4]):
+        pairs_txt.append((mutate(rng, f, 0.1), mutate(rng, r, 0.1)))
+    pairs = [(reference.centered_word(f), reference.centered_word(r)) for f, r in pairs_txt]
+    to, tr = _sessions(oracle, reference, seqs, [1.0 + 0.3 * (i % 4) for i in range(len(seqs))], optimize_5=1, optimize_3=1, **sess)
+    bo, br = _sessions(oracle, reference, bgs, None, optimize_5=1, optimize_3=1, **sess)
+    assert to.select(pairs) == tr.select(pairs)
+    bthr = float(np.float32(0.8) * np.float32(0.9))
+    assert bo.select(pairs, threshold=bthr, min_len_override=16) == br.select(pairs, threshold=bthr, min_len_override=16)
+    changed = 0
+    for p in pairs:
+        ro = optimize(oracle, to, bo, p, **case)
+        rr = optimize(reference, tr, br, p, **case)
+        assert ro == rr, (p, ro, rr)
+        changed += ro[0] != p
+    assert changed > 0
