@@ -257,6 +257,8 @@ def main():
                                  "each target once per pass for all pairs, so frac may exceed 1 -- see traffic for measured HBM bytes",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "traffic_GBps": (traffic / kern_s / 1e9) if (traffic and kern_s > 0) else None,
+                         "traffic_frac": (traffic / kern_s / 1e9 / HBM_PEAK_GBPS) if (traffic and kern_s > 0) else None,
                          "kernel_ms": kern_s * 1e3, "launches": int(scan_launches),
                          "algorithmic_bytes_per_launch": evals_per_launch * b_eval},
         }

@@ -1580,7 +1580,7 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 			else{
 				if(need_plain && (rc = launch_scan2(ctx, S, tab_plain, ncand, sink, d_tab_plain, d_bias_plain, nullptr, S.n_tiles, d_map_plain)) != PCR_OK) return rc;
 				if(!or_seed.empty()){
-					const bool cand_lds = ncand <= SEED_CAND_LDS;
+					const bool cand_lds = ncand <= SEED_CAND_LDS;   // (candidates read from global to fit 8 workgroups per CU: 140 vs 102 us)
 					const size_t dyn = cand_lds ? (size_t)ncand*(2*sizeof(uint4) + sizeof(uint32_t)) : 0;
 					// persistent workgroups: exactly as many as are resident at once (a partial second round would
 					// run alone at the end), asked of the runtime for this kernel and its dynamic LDS size

@@ -17,6 +17,7 @@ CONFIGS = {
     "C1": dict(T=100, L=1000, P=5),
     "C2": dict(T=10000, L=10000, P=50),
     "C3": dict(T=50000, L=2000, P=50, B=10000, LB=2000),
+    "C4_shard": dict(T=625, L=5000000, P=50),            # one of the 8 shards of C4 (5 000 genomes x 5 Mb); 1.56 GB packed
     "C5_shard": dict(T=12500, L=10000, P=50, degenerate=3),
 }
 
@@ -35,6 +36,7 @@ def make_sequences(T, L, seed, family=50, divergence=0.03, chunk=256):
     nb = (L + 1) // 2
     packed = np.empty(T * nb, dtype=np.uint8)
     fam_of = np.arange(T) // family
+    chunk = max(1, min(chunk, (32 << 20) // max(L, 1)))     # bound the temporaries (~20 B per base of a chunk)
     for lo in range(0, T, chunk):
         hi = min(T, lo + chunk)
         c = roots[fam_of[lo:hi]].copy()
@@ -89,7 +91,7 @@ def workload(name, seed_offset=0, scale=1.0):
     """-> dict(packed, byte_offsets, lengths, pairs, T, L, P).  `scale` < 1 shrinks T (CPU baselines)."""
     cfg = dict(CONFIGS[name])
     T = max(1, int(round(cfg["T"] * scale)))
-    seed = BASE_SEED + {"C1": 1, "C2": 2, "C3": 3, "C5_shard": 5}[name] + 1000 * seed_offset
+    seed = BASE_SEED + {"C1": 1, "C2": 2, "C3": 3, "C4_shard": 4, "C5_shard": 5}[name] + 1000 * seed_offset
     packed, off, lens = make_sequences(T, cfg["L"], seed)
     pairs = make_pairs(packed, off, lens, cfg["P"], seed, degenerate=cfg.get("degenerate", 0))
     return dict(packed=packed, byte_offsets=off, lengths=lens, pairs=pairs, T=T, L=cfg["L"], P=cfg["P"], name=name)
