@@ -12,13 +12,19 @@
 //               window that Sequence::pack emits (sequence.cpp:127-153 filters applied).
 //   irr[]     : explicit irregular words (pcr_host.hpp).
 // Kernels
-//   k_transpose, k_valid  : load-time index build (replaces Sequence::operator= + the filter half of pack)
-//   k_scan, k_scan_irr    : oligo x window match counts + per-(sequence,candidate) running max
-//                           (select_words.cpp:88-117 over the implicit word index)
-//   k_finalize            : per-sequence arg-max-with-ties filter, sort, dedupe -> the device word DB
-//                           (select_words.cpp:100-138)
-//   k_match, k_pair       : match_words / find_oligo_match / find_amplicon_match / update_identity /
-//                           sqrtf(f*r) test (optimize.cpp:209-301, pcr_assay.cpp:12-69,338-441,544-578)
+//   k_transpose, k_valid, k_tile_degen : load-time index build (replaces Sequence::operator= + the filter half of pack)
+//   k_stage                : per-pass tables out of host-mapped memory + clearing of the pass's control block
+//   k_seed (+ scan_irr_block), k_scan2, k_scan, k_scan_irr :
+//                            oligo x window match counts + per-(sequence,candidate) running max
+//                            (select_words.cpp:88-117 over the implicit word index); pcr_scan_seed.inc,
+//                            pcr_scan_bitsliced.inc
+//   k_touched, k_finalize  : per-sequence arg-max-with-ties filter, sort, dedupe -> the device word DB
+//                            (select_words.cpp:100-138)
+//   k_match, k_pair        : match_words / find_oligo_match / find_amplicon_match / update_identity /
+//                            sqrtf(f*r) test (optimize.cpp:209-301, pcr_assay.cpp:12-69,338-441,544-578)
+//   k_pair_moves           : the same sweep for the trial words of a local-search move (optimize_pcr.cpp)
+//   k_sw, k_bg_*, k_mx_*   : SeqOverlap Smith-Waterman and the background / multiplex screens (pcr_sw.inc)
+//   thermo::k_thermo       : NucCruc (pcr_thermo.inc)
 #include <hip/hip_runtime.h>
 
 #include <stdint.h>
@@ -759,7 +765,7 @@ struct SeqSet {
 	uint32_t n_tiles = 0, n_irr = 0;
 	DevBuf<uint32_t> irr_perm; uint32_t irr_size_count[256];   // irregular words by size counter, largest first
 	DevBuf<uint4> planes;
-	DevBuf<uint32_t> valid, nib, tb, blk_seq, tile_seq, tile_pos0, irr_off, seg_lo, seg_hi, degen_tiles;
+	DevBuf<uint32_t> valid, nib, tb, blk_seq, tile_seq, tile_pos0, irr_off, degen_tiles;
 	DevBuf<uint8_t> tile_degen; uint32_t n_degen_tiles = 0;
 	DevBuf<uint64_t> d_len, d_blk_off, d_nblk_real;
 	DevBuf<uint8_t> d_active;
@@ -778,7 +784,7 @@ struct SeqSet {
 	void release()
 	{
 		irr_perm.release(); planes.release(); valid.release(); nib.release(); tb.release(); degen_tiles.release(); tile_degen.release(); blk_seq.release(); tile_seq.release(); tile_pos0.release();
-		irr_off.release(); seg_lo.release(); seg_hi.release(); d_len.release(); d_blk_off.release();
+		irr_off.release(); d_len.release(); d_blk_off.release();
 		d_nblk_real.release(); d_active.release(); irr.release(); db.release(); touched.release(); ctrl.release(); codes.release(); d_code_off.release();
 	}
 };
@@ -793,8 +799,7 @@ struct pcr_ctx {
 	pcrhost::PackFilter filt;
 	SeqSet sets[2];
 	// scratch
-	DevBuf<uint4> cand_fwd, cand_rc;
-	DevBuf<uint32_t> cand_floor, best, counters, mask, status, tab, bias;
+	DevBuf<uint32_t> best, counters, mask, status;
 	int scan_version = 3;
 	DevBuf<Hit> hits;
 	DevBuf<uint64_t> bits_fr, bits_rf;
@@ -827,7 +832,7 @@ struct pcr_ctx {
 	};
 	std::vector<Pending> pending;
 	DevBuf<uint8_t> arena;
-	const uint4 *d_cand_fwd = nullptr, *d_cand_rc = nullptr; const uint32_t *d_cand_floor = nullptr, *d_tab = nullptr, *d_bias = nullptr;
+	const uint4 *d_cand_fwd = nullptr, *d_cand_rc = nullptr; const uint32_t *d_cand_floor = nullptr;
 	const OligoDev *d_oligos = nullptr;
 	// host-side phase timers (PCRAMP_TIMING=1: printed by pcr_destroy)
 	bool timing = false; double t_host[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint64_t n_timed = 0;
@@ -1202,12 +1207,12 @@ void pcr_destroy(pcr_ctx *ctx)
 	}
 	for(auto &pr : ctx->prof_events){ (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
 	for(int s = 0;s < 2;++s) ctx->sets[s].release();
-	ctx->cand_fwd.release(); ctx->cand_rc.release(); ctx->cand_floor.release(); ctx->best.release();
+	ctx->best.release();
 	ctx->counters.release(); ctx->mask.release(); ctx->status.release(); ctx->hits.release();
 	ctx->bits_fr.release(); ctx->bits_rf.release(); ctx->arena.release(); ctx->fin_scratch.release();
 	for(auto &sl : ctx->stage){ if(sl.host) (void)hipHostFree(sl.host); if(sl.done) (void)hipEventDestroy(sl.done); }
 	if(ctx->mail) (void)hipHostFree(ctx->mail);
-	ctx->oligos.release(); ctx->tab.release(); ctx->bias.release(); ctx->sw_jobs.release(); ctx->sw_out.release(); ctx->sw_q.release(); ctx->sw_qlen.release(); ctx->sw_t.release(); ctx->entry_codes.release(); ctx->entry_lens.release(); ctx->amp_recs.release(); ctx->bg_pairs.release(); ctx->th_jobs.release(); ctx->th_out.release(); ctx->th_dg.release(); ctx->th_scratch_i.release(); ctx->th_scratch_s.release();
+	ctx->oligos.release(); ctx->sw_jobs.release(); ctx->sw_out.release(); ctx->sw_q.release(); ctx->sw_qlen.release(); ctx->sw_t.release(); ctx->entry_codes.release(); ctx->entry_lens.release(); ctx->amp_recs.release(); ctx->bg_pairs.release(); ctx->th_jobs.release(); ctx->th_out.release(); ctx->th_dg.release(); ctx->th_scratch_i.release(); ctx->th_scratch_s.release();
 	if(ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
@@ -1296,8 +1301,6 @@ int pcr_load_sequences(pcr_ctx *ctx, pcr_set which, const uint8_t *packed4, cons
 	if((rc = S.d_blk_off.ensure(n + 1)) != PCR_OK) return fail(rc);
 	if((rc = S.d_nblk_real.ensure(n)) != PCR_OK) return fail(rc);
 	if((rc = S.d_active.ensure(n)) != PCR_OK) return fail(rc);
-	if((rc = S.seg_lo.ensure(n)) != PCR_OK) return fail(rc);
-	if((rc = S.seg_hi.ensure(n)) != PCR_OK) return fail(rc);
 #define H2D(dst, src, bytes) do{ if((bytes) > 0){ hipError_t e_ = hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice); \
 	if(e_ != hipSuccess){ g_err = std::string("hipMemcpy: ") + hipGetErrorString(e_); return fail(PCR_ERR_DEVICE); } } }while(0)
 	{   // one transfer for all sequences (a copy per sequence was 10 000 copy-engine packets at C2)
