@@ -77,3 +77,55 @@ def test_full_c2_properties(c2):
     finally:
         a.close()
         b.close()
+
+
+def test_megabase_sequences_and_table_overflow():
+    """(a) Genome-sized sequences (C4's shape, 3 Mb each): seed scan == bit-sliced scan, sites planted near the
+    far end are found.  (b) More seed codes than the table admits (hundreds of pairs with 5'/3' shifts): the
+    pass falls back to the bit-sliced scan for everything and still equals it."""
+    rs = np.random.RandomState(123)
+    L = 3_000_000
+    from pcramp_amd import words as W
+    codes = [2 ** rs.randint(0, 4, size=L).astype(np.uint8) for _ in range(3)]
+    codes.append(codes[0].copy())
+    flip = rs.randint(0, L, size=L // 50)
+    codes[3][flip] = 2 ** rs.randint(0, 4, size=flip.size).astype(np.uint8)     # ~1.5 % divergent copy
+    packed = np.concatenate([W.pack_codes(c) for c in codes])
+    nb = (L + 1) // 2
+    off = np.arange(4, dtype=np.uint64) * np.uint64(nb)
+    lens = np.full(4, L, dtype=np.uint64)
+    comp = {1: 8, 2: 4, 4: 2, 8: 1}
+    pairs = []
+    for pos in (100, 1_000_000, 2_999_700, L - 200, 1234567):
+        f = codes[0][pos:pos + 21]
+        r = np.array([comp[int(v)] for v in codes[0][pos + 120:pos + 142][::-1]], dtype=np.uint8)
+        pairs.append((W.centered_word(f), W.centered_word(r)))
+    a, b = _screener(None), _screener(2)
+    try:
+        res = []
+        for d in (a, b):
+            d.load_sequences(packed, off, lens)
+            n = d.select_words(pairs, float(np.float32(1.0) * np.float32(0.9)), 18)
+            bits, fr, rf, cov = d.amplify(pairs, 1.0, 1.0, 80, 200, False)
+            res.append((n, d.entries(), fr, rf))
+        assert res[0][0] == res[1][0] and res[0][1] == res[1][1]
+        assert np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][3], res[1][3])
+        assert res[0][2][:, 0].all()                       # every planted pair amplifies sequence 0 in F(+)/R(-) orientation
+        # (b) table overflow
+        wl = synth.workload("C2", 0, 0.02)
+        many = []
+        for k in range(900):
+            i = rs.randint(0, wl["T"])
+            c = synth.sequence_codes(wl["packed"], wl["byte_offsets"], wl["lengths"], i)
+            p = rs.randint(0, wl["L"] - 200)
+            many.append((W.centered_word(c[p:p + rs.randint(18, 26)]),
+                         W.centered_word(np.array([comp[int(v)] for v in c[p + 120:p + 120 + rs.randint(18, 26)][::-1]], dtype=np.uint8))))
+        out = []
+        for d in (a, b):
+            d.load_sequences(wl["packed"], wl["byte_offsets"], wl["lengths"])
+            n = d.select_words(many, float(np.float32(1.0) * np.float32(0.9)), 18, True, True)
+            out.append((n, d.entries()))
+        assert out[0] == out[1] and out[0][0] > 0
+    finally:
+        a.close()
+        b.close()
