@@ -62,6 +62,8 @@ struct Hit { uint64_t key; uint32_t cand; uint32_t cnt; };
 // host-mapped mailbox slot: a pass's counters, then its sequence number (release store)
 struct PassMail { volatile uint32_t counters[4]; volatile uint32_t seq; uint32_t pad[11]; };
 
+constexpr uint32_t N_TOUCHED_UNKNOWN_DEV = 0xFFFFFFFFu;   // published instead of a touched count by the fused tail
+
 struct IrrDev { Planes w; int32_t loc; uint32_t seq; uint32_t meta; /* strand | cws<<8 | ord<<16 */ uint32_t local_id; };
 
 struct DevEntry { Planes w; int32_t loc; uint32_t seq; uint32_t strand; uint32_t pad; };
@@ -731,6 +733,140 @@ __global__ void k_pair_moves(const DevEntry *__restrict__ db, uint32_t n, uint32
 	}
 }
 
+// The whole tail of a fused pass in ONE launch (k_touched + k_finalize + k_match + k_pair, for the common
+// case of 64-slot buckets and <= 128 oligos): one wave per SEQUENCE of the set -- a wave whose sequence
+// collected no hit leaves at once -- keeps the final-maximum hits, sorts and dedupes them (one key per lane),
+// materialises the sequence's DB entries (global, for later callers, and LDS), builds their oligo masks and
+// runs k_pair's sweep over them out of LDS.  The touched list is not built (ensure_touched() does it on
+// demand); the has_split range error goes to counters[1]; block 0 publishes the pass's counters.
+constexpr int POST_WAVES = 8;
+constexpr uint32_t POST_CAP = 64, POST_MASK_WORDS = 4;
+struct PostShared {
+	OligoDev ol[32*POST_MASK_WORDS];           // the pass's oligo table, staged once per workgroup
+	uint64_t keys[POST_WAVES][POST_CAP]; DevEntry ent[POST_WAVES][POST_CAP]; uint32_t msk[POST_WAVES][POST_CAP][POST_MASK_WORDS];
+};
+
+__global__ __launch_bounds__(64*POST_WAVES) void k_post(const Hit *__restrict__ hits, const uint32_t *__restrict__ seq_count,
+	const uint32_t *__restrict__ best, uint32_t ncand, const uint4 *__restrict__ planes, const uint64_t *__restrict__ blk_off,
+	const IrrDev *__restrict__ irr, const uint32_t *__restrict__ irr_off, DevEntry *__restrict__ db, uint32_t *__restrict__ seg_hi,
+	uint32_t *__restrict__ counters, uint32_t epoch, uint32_t n_seq,
+	const OligoDev *__restrict__ oligos, uint32_t n_pairs, uint32_t mask_words,
+	const uint64_t *__restrict__ len, const uint8_t *__restrict__ active, int32_t amp_min, int32_t amp_max, float ident_thr, int use_taq,
+	uint64_t *__restrict__ bits_fr, uint64_t *__restrict__ bits_rf, uint64_t bit_words, PassMail *pub_mail, uint32_t pub_seq)
+{
+	__shared__ PostShared sh;
+	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+	if(pub_mail && blockIdx.x == 0 && wave == 0){              // every scan of the pass is complete: its counters -> host mailbox
+		if(lane < 4) pub_mail->counters[lane] = (lane == 3) ? N_TOUCHED_UNKNOWN_DEV : counters[lane];
+		__threadfence_system();
+		__builtin_amdgcn_wave_barrier();
+		if(lane == 0) __hip_atomic_store((uint32_t *)&pub_mail->seq, pub_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+	}
+	const uint32_t seq = blockIdx.x*POST_WAVES + wave;
+	const uint32_t n = (seq < n_seq) ? min(seq_count[seq], POST_CAP) : 0u;
+	// a workgroup with at least one busy wave stages the oligo table (a chain of dependent scalar loads per
+	// oligo made the match loop the longest part of the wave's life)
+	if(__syncthreads_or((int)n)){
+		const uint32_t nw = 2*n_pairs*(uint32_t)(sizeof(OligoDev)/4);
+		for(uint32_t i = threadIdx.x;i < nw;i += 64*POST_WAVES) ((uint32_t *)sh.ol)[i] = ((const uint32_t *)oligos)[i];
+		__syncthreads();
+	}
+	if(n == 0) return;                                          // seg_hi[seq] stays 0 = empty
+	uint64_t *keys = sh.keys[wave];
+	DevEntry *ent = sh.ent[wave];
+	// ---- k_finalize: one key per lane
+	uint64_t k = ~0ull;
+	if(lane < n){
+		const Hit h = hits[(size_t)seq*POST_CAP + lane];
+		if(((epoch << 8) | h.cnt) == best[(size_t)seq*ncand + h.cand]) k = h.key;
+	}
+	keys[lane] = k;
+	wave_sync();
+	uint32_t np2 = 1; while(np2 < n) np2 <<= 1;                // sentinels beyond n are already in place: sort only the first np2 keys
+	for(uint32_t kk = 2;kk <= np2;kk <<= 1){
+		for(uint32_t j = kk >> 1;j > 0;j >>= 1){
+			const uint32_t l = lane ^ j;
+			if(l > lane && l < np2){
+				const uint64_t a = keys[lane], b = keys[l];
+				const bool up = ((lane & kk) == 0);
+				if((a > b) == up){ keys[lane] = b; keys[l] = a; }
+			}
+			wave_sync();
+		}
+	}
+	k = keys[lane];
+	const bool distinct = k != ~0ull && (lane == 0 || keys[lane - 1] != k);
+	const uint64_t dmask = __ballot(distinct);
+	const uint32_t run = (uint32_t)__builtin_popcountll(dmask);
+	const uint32_t rank = (uint32_t)__builtin_popcountll(dmask & ((1ull << lane) - 1ull));
+	if(lane == 0) seg_hi[seq] = seq*POST_CAP + run;
+	if(distinct){
+		DevEntry e;
+		materialise_entry(k, planes, blk_off, irr, irr_off, e);
+		db[(size_t)seq*POST_CAP + rank] = e;
+		ent[rank] = e;
+	}
+	wave_sync();
+	if(n_pairs == 0) return;
+	// ---- k_match: lane = entry, oligos walked with scalar operands
+	const uint32_t n_oligo = 2*n_pairs;
+	DevEntry me; me.w.a = me.w.c = me.w.g = me.w.t = 0; me.loc = 0; me.seq = seq; me.strand = 0; me.pad = 0;
+	if(lane < run) me = ent[lane];
+	for(uint32_t mw = 0;mw < mask_words;++mw){
+		uint32_t bits = 0;
+		const uint32_t o_end = min(n_oligo, (mw + 1)*32);
+#pragma unroll 4
+		for(uint32_t o = mw*32;o < o_end;++o){
+			const Planes m = sh.ol[o].m;
+			const uint32_t cnt = __popc((me.w.a & m.a) | (me.w.c & m.c) | (me.w.g & m.g) | (me.w.t & m.t));
+			bits |= (uint32_t)(cnt >= sh.ol[o].floor2) << (o & 31);
+		}
+		sh.msk[wave][lane][mw] = (lane < run) ? bits : 0u;
+	}
+	wave_sync();
+	// ---- k_pair: lane = plus-strand entry i, walks the later entries of the sequence
+	if(lane >= run || me.strand != 1 || !active[seq]) return;           // optimize.cpp:281
+	const int32_t L = (int32_t)len[seq];
+	const uint64_t base = blk_off[seq];
+	for(uint32_t j = lane + 1;j < run;++j){
+		const DevEntry ej = ent[j];
+		if(ej.loc - me.loc > amp_max + 128) break;
+		if(ej.strand != 2) continue;
+		for(uint32_t w = 0;w < mask_words;++w){
+			const uint32_t mi = sh.msk[wave][lane][w], mj = sh.msk[wave][j][w];
+			uint32_t fr = mi & (mj >> 1) & 0x55555555u;
+			uint32_t rf = (mi >> 1) & mj & 0x55555555u;
+			uint32_t any = fr | rf;
+			while(any){
+				const uint32_t bit = __ffs(any) - 1;
+				any &= any - 1;
+				const uint32_t pair = (w*32 + bit) >> 1;
+				if(pair >= n_pairs) break;
+				const OligoDev F = sh.ol[2*pair], R = sh.ol[2*pair + 1];
+				for(int orient = 0;orient < 2;++orient){
+					if(!(((orient == 0) ? fr : rf) >> bit & 1u)) continue;
+					const OligoDev &P = (orient == 0) ? F : R;   // plus-role oligo
+					const OligoDev &M = (orient == 0) ? R : F;   // minus-role oligo
+					if(me.loc + P.stop >= ej.loc - M.stop) continue;                       // pcr_assay.cpp:367-370
+					int32_t amp_start = me.loc + P.start;
+					const int32_t amp_stop = min(ej.loc - M.start, L - 1);
+					int32_t amp_len = amp_stop - amp_start + 1;
+					if(amp_len < amp_min || amp_len > amp_max) continue;
+					if(amp_start < 0){ amp_len += amp_start; amp_start = 0; }
+					if(amp_len < 0 || amp_start + amp_len > L){ atomicOr(&counters[1], 1u); continue; }   // sequence.cpp:306 throw
+					if(has_split(planes, base, amp_start, amp_len)) continue;
+					const float f = identity(F, (orient == 0) ? me.w : ej.w, use_taq);
+					const float r = identity(R, (orient == 0) ? ej.w : me.w, use_taq);
+					if(__fsqrt_rn(__fmul_rn(f, r)) >= ident_thr){                        // pcr_assay.cpp:572-576
+						uint64_t *dst = (orient == 0) ? bits_fr : bits_rf;
+						atomicOr((unsigned long long *)&dst[(size_t)pair*bit_words + (seq >> 6)], 1ull << (seq & 63));
+					}
+				}
+			}
+		}
+	}
+}
+
 #include "pcr_sw.inc"
 #include "pcr_thermo.inc"
 
@@ -780,6 +916,7 @@ struct SeqSet {
 	DevBuf<uint32_t> touched;     // sequences holding DB entries (k_touched)
 	DevBuf<uint32_t> ctrl;        // [0..7] counters | [8, 8+n) per-sequence hit counts | [8+n, 8+2n) seg_hi : one memset per pass
 	uint32_t n_touched = 0;
+	bool touched_built = false;   // touched[] / counters[3] hold the list of the last pass (the fused tail does not build it)
 	uint32_t *d_seg_hi = nullptr;
 	void release()
 	{
@@ -1013,6 +1150,7 @@ int mail_wait(pcr_ctx *ctx, uint32_t seq, uint32_t out[4])
 struct FusedAmp {
 	const pcr_pair *pairs; uint32_t n_pairs; const pcr_amplify_args *a; uint64_t *d_fr, *d_rf;
 	bool staged = false; const OligoDev *d_oligos = nullptr; uint32_t pub_seq = 0; const uint32_t *pub_counters = nullptr;
+	bool posted = false;       // k_post ran the whole tail (amplicon screen included)
 };
 
 void build_oligos(const pcr_pair *pairs, uint32_t n_pairs, const pcr_amplify_args *a, std::vector<OligoDev> &ol)
@@ -1025,9 +1163,23 @@ void build_oligos(const pcr_pair *pairs, uint32_t n_pairs, const pcr_amplify_arg
 	}
 }
 
+// The fused tail (k_post) leaves the DB in place but builds no touched list: do it for the callers that walk it.
+int ensure_touched(pcr_ctx *ctx, SeqSet &S)
+{
+	if(S.touched_built || !S.have_db || !S.ctrl.p) return PCR_OK;
+	hipLaunchKernelGGL(k_touched, dim3((S.n + 255)/256), dim3(256), 0, ctx->stream, S.ctrl.p + 8, S.n, S.ctrl.p, S.touched.p);
+	HIP_TRY(hipGetLastError());
+	uint32_t n = 0;
+	HIP_TRY(hipMemcpyAsync(&n, S.ctrl.p + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	S.n_touched = n; S.n_entries = n ? 1 : 0; S.touched_built = true;
+	return PCR_OK;
+}
+
 int amplify_launch(pcr_ctx *ctx, SeqSet &S, const pcr_pair *pairs, uint32_t n_pairs, const pcr_amplify_args *a,
 	uint64_t *d_fr, uint64_t *d_rf, const FusedAmp *fa = nullptr)
 {
+	{ const int erc = ensure_touched(ctx, S); if(erc != PCR_OK) return erc; }
 	if(!S.have_db){ g_err = "pcr_amplify: no word DB (call pcr_select_words first)"; return PCR_ERR_STATE; }
 	const uint64_t words = (S.n + 63)/64;
 	const size_t bits_bytes = (size_t)n_pairs*words*sizeof(uint64_t);
@@ -1628,8 +1780,23 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 				S.d_active.p, ctx->d_cand_fwd, ctx->d_cand_floor, ncand, sink);
 			HIP_TRY(hipGetLastError());
 		}
+		if(async && fa && fa->staged && cap == POST_CAP && 2*fa->n_pairs <= 32*POST_MASK_WORDS){
+			// the whole tail -- DB finalisation and the amplicon screen -- in one launch
+			++ctx->mail_seq;
+			const uint64_t bw = (S.n + 63)/64;
+			hipLaunchKernelGGL(k_post, dim3((S.n + POST_WAVES - 1)/POST_WAVES), dim3(64*POST_WAVES), 0, ctx->stream, ctx->hits.p, d_seq_count,
+				ctx->best.p, ncand, S.planes.p, S.d_blk_off.p, S.irr.p, S.irr_off.p, S.db.p, S.d_seg_hi, d_counters, ctx->epoch, S.n,
+				fa->d_oligos, fa->n_pairs, (2*fa->n_pairs + 31)/32, S.d_len.p, S.d_active.p, fa->a->amp_min, fa->a->amp_max,
+				fa->a->ident_threshold, fa->a->use_taq_mama, fa->d_fr, fa->d_rf, bw, ctx->mail_dev + (ctx->mail_seq % pcr_ctx::MAIL_RING), ctx->mail_seq);
+			HIP_TRY(hipGetLastError());
+			fa->posted = true;
+			S.db_cap = cap; S.n_slots = n_slots;
+			S.n_touched = N_TOUCHED_UNKNOWN; S.n_entries = 1; S.have_db = true; S.touched_built = false;
+			return PCR_OK;
+		}
 		hipLaunchKernelGGL(k_touched, dim3((S.n + 255)/256), dim3(256), 0, ctx->stream, d_seq_count, S.n, d_counters, S.touched.p);
 		HIP_TRY(hipGetLastError());
+		S.touched_built = true;
 		uint32_t np2 = 1; while(np2 < cap) np2 <<= 1;
 #define FIN_ARGS ctx->hits.p, d_seq_count, cap, ctx->best.p, ncand, S.planes.p, S.d_blk_off.p, S.irr.p, S.irr_off.p, S.db.p, S.d_seg_hi, \
 	d_counters, ctx->epoch, S.touched.p
@@ -1687,7 +1854,12 @@ int drain(pcr_ctx *ctx)
 		uint32_t c[4];
 		if((rc = mail_wait(ctx, pend[i].seq, c)) != PCR_OK) return rc;
 		SeqSet &S = ctx->sets[pend[i].which];
-		if(!(c[0] & 1u)){ S.n_touched = c[3]; S.n_entries = c[3] ? 1 : 0; continue; }
+		if(c[3] == N_TOUCHED_UNKNOWN_DEV && (c[1] & 1u)){ g_err = "Sequence::has_split: range is out of bounds"; return PCR_ERR_RANGE; }   // sequence.cpp:306-308 (fused tail)
+		if(!(c[0] & 1u)){
+			if(c[3] == N_TOUCHED_UNKNOWN_DEV){ S.n_touched = N_TOUCHED_UNKNOWN; S.n_entries = 1; }
+			else{ S.n_touched = c[3]; S.n_entries = c[3] ? 1 : 0; }
+			continue;
+		}
 		uint32_t want = ctx->bucket_cap*2;
 		while(want < c[2] && want < MAX_BUCKET_CAP_GLOBAL) want *= 2;
 		ctx->bucket_cap = std::min(want, MAX_BUCKET_CAP_GLOBAL);
@@ -1722,7 +1894,7 @@ int pcr_screen_device(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32
 	FusedAmp fa; fa.pairs = pairs; fa.n_pairs = n_pairs; fa.a = args; fa.d_fr = d_bits_fr; fa.d_rf = d_bits_rf;
 	int rc = select_impl(ctx, which, pairs, n_pairs, optimize_5, optimize_3, select_threshold, min_oligo_length, nullptr, true, &fa);
 	if(rc != PCR_OK) return rc;
-	if((rc = amplify_launch(ctx, ctx->sets[which], pairs, n_pairs, args, d_bits_fr, d_bits_rf, &fa)) != PCR_OK) return rc;
+	if(!fa.posted && (rc = amplify_launch(ctx, ctx->sets[which], pairs, n_pairs, args, d_bits_fr, d_bits_rf, &fa)) != PCR_OK) return rc;
 	if(ctx->mail_seq != seq0){                                        // a pass was enqueued (not the empty-input shortcut)
 		pcr_ctx::Pending p;
 		p.seq = ctx->mail_seq; p.which = (int)which; p.pairs.assign(pairs, pairs + n_pairs); p.opt5 = optimize_5; p.opt3 = optimize_3;
@@ -1805,6 +1977,7 @@ int pcr_move_coverage(pcr_ctx *ctx, pcr_set which, const pcr_pair *base, int sid
 	HIP_TRY(hipSetDevice(ctx->device));
 	SeqSet &S = ctx->sets[which];
 	if(!S.have_db){ g_err = "pcr_move_coverage: no word DB (call pcr_select_words first)"; return PCR_ERR_STATE; }
+	{ const int erc = ensure_touched(ctx, S); if(erc != PCR_OK) return erc; }
 	const uint64_t words = (S.n + 63)/64;
 	const size_t total = (size_t)n_variants*words;
 	if(coverage){ for(uint32_t v = 0;v < n_variants;++v) coverage[v] = 0.0f; }
@@ -2086,6 +2259,7 @@ int pcr_background_match(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uin
 	HIP_TRY(hipSetDevice(ctx->device));
 	SeqSet &S = ctx->sets[which];
 	if(!S.have_db){ g_err = "pcr_background_match: no word DB (call pcr_select_words first)"; return PCR_ERR_STATE; }
+	{ const int erc = ensure_touched(ctx, S); if(erc != PCR_OK) return erc; }
 	const uint64_t words = (S.n + 63)/64;
 	const size_t total = (size_t)n_pairs*words;
 	if(total) memset(bits, 0, total*sizeof(uint64_t));
