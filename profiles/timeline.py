@@ -1,15 +1,20 @@
 #!/usr/bin/env python3
 """Print the kernel/copy timeline of the last bench step from a rocprofv3 csv trace directory
 (rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d DIR -- python3 bench.py ...)."""
-import csv, glob, re, sys
+import csv, glob, os, re, sys
 
 d = sys.argv[1]
 ev = []
-for f in glob.glob(d + "/*/*_kernel_trace.csv"):
+def newest(pattern):      # gpurun merges every call's files into the same directory: take the latest run's
+    fs = glob.glob(pattern)
+    return [max(fs, key=os.path.getmtime)] if fs else []
+
+
+for f in newest(d + "/*/*_kernel_trace.csv"):
     for r in csv.DictReader(open(f)):
         n = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"]).split("(")[0][:44]
         ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), n))
-for f in glob.glob(d + "/*/*_memory_copy_trace.csv"):
+for f in newest(d + "/*/*_memory_copy_trace.csv"):
     for r in csv.DictReader(open(f)):
         ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "COPY " + r["Direction"]))
 ev.sort()
