@@ -92,6 +92,13 @@ def load_library():
     if not os.path.exists(path):
         raise PcrError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(or make -C pcramp_amd/csrc); there is no CPU fallback" % path)
+    # PyTorch-ROCm bundles its own HIP runtime: whichever libamdhip64 is loaded first serves the whole process, and
+    # a process in which this library came first cannot initialise torch.cuda afterwards ("No HIP GPUs are
+    # available").  Callers use torch for device buffers and RCCL, so let it load first when it is installed.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(path)
     L.pcr_last_error.restype = C.c_char_p
     L.pcr_create.restype = C.c_void_p
