@@ -520,352 +520,7 @@ __global__ __launch_bounds__(FINBIG_THREADS) void k_finalize_big(const Hit *__re
 	}
 }
 
-// ============================================================================== amplicon screen
-// match_words (optimize.cpp:291-301) of every assay oligo against every DB entry:
-// mask[e][o/32] bit o%32 = entry matches oligo o at or above unsigned(size*thr^2).
-// DB threads: thread g covers slot g%cap of the (g/cap)-th touched sequence.
-__device__ __forceinline__ bool db_slot(uint32_t g, uint32_t n, uint32_t cap, const uint32_t *__restrict__ touched,
-	const uint32_t *__restrict__ seg_hi, uint32_t &slot)
-{
-	if(g >= n) return false;
-	const uint32_t seq = touched[g/cap];
-	slot = seq*cap + g % cap;
-	return slot < seg_hi[seq];
-}
-
-// One wave per touched sequence; a lane = (entry parity, oligo % 32): two DB entries against 32 oligos per
-// step, the 64 compare results leave as one ballot.  (One lane per DB slot walked the oligo list serially:
-// with a handful of filled slots per sequence that was a chain of dependent scalar loads, 20 us at C2.)
-constexpr int MATCH_WAVES = 4;
-__global__ __launch_bounds__(64*MATCH_WAVES) void k_match(const DevEntry *__restrict__ db, uint32_t n_touched, const uint32_t *__restrict__ n_touched_dev, uint32_t cap,
-	const uint32_t *__restrict__ touched, const uint32_t *__restrict__ seg_hi, const OligoDev *__restrict__ oligos, uint32_t n_oligo,
-	uint32_t mask_words, uint32_t *__restrict__ mask, uint32_t *__restrict__ status,
-	const uint32_t *__restrict__ pub_counters, PassMail *pub_mail, uint32_t pub_seq)
-{
-	if(blockIdx.x == 0 && threadIdx.x == 0 && status) status[0] = 0;
-	if(pub_mail && blockIdx.x == 0 && threadIdx.x < 64){        // the pass's counters -> host mailbox (k_publish's job in the fused pass)
-		if(threadIdx.x < 4) pub_mail->counters[threadIdx.x] = pub_counters[threadIdx.x];
-		__threadfence_system();
-		__builtin_amdgcn_wave_barrier();
-		if(threadIdx.x == 0) __hip_atomic_store((uint32_t *)&pub_mail->seq, pub_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-	}
-	if(n_touched_dev) n_touched = *n_touched_dev;                // asynchronous passes: the host does not know it yet
-	const uint32_t lane = threadIdx.x & 63u, sub = lane >> 5, ol = lane & 31u;
-	for(uint32_t t_idx = blockIdx.x*MATCH_WAVES + (threadIdx.x >> 6);t_idx < n_touched;t_idx += gridDim.x*MATCH_WAVES){
-	const uint32_t seq = touched[t_idx];
-	const uint32_t lo = seq*cap, n_e = seg_hi[seq] - lo;         // filled slots [lo, seg_hi[seq])
-	for(uint32_t e0 = 0;e0 < n_e;e0 += 2){
-		const bool have = e0 + sub < n_e;
-		const uint32_t i = lo + e0 + sub;
-		Planes w; w.a = w.c = w.g = w.t = 0;
-		if(have) w = db[i].w;
-		for(uint32_t mw = 0;mw < mask_words;++mw){
-			const uint32_t o = mw*32 + ol;
-			bool ok = false;
-			if(have && o < n_oligo){
-				const Planes m = oligos[o].m;
-				ok = (uint32_t)__popc((w.a & m.a) | (w.c & m.c) | (w.g & m.g) | (w.t & m.t)) >= oligos[o].floor2;
-			}
-			const uint64_t bal = __ballot(ok);
-			if(have && ol == 0) mask[(size_t)i*mask_words + mw] = sub ? (uint32_t)(bal >> 32) : (uint32_t)bal;
-		}
-	}
-	}
-}
-
-__device__ __forceinline__ uint32_t nibble_at(const Planes &p, int k)
-{
-	return ((p.a >> k) & 1u) | (((p.c >> k) & 1u) << 1) | (((p.g >> k) & 1u) << 2) | (((p.t >> k) & 1u) << 3);
-}
-
-__device__ __forceinline__ bool nondegen(uint32_t v) { return v == 1 || v == 2 || v == 4 || v == 8; }   // base_table.h:125
-
-__device__ __forceinline__ int taq_idx(uint32_t v) { return (v == 2) ? 0 : (v == 4) ? 1 : (v == 1) ? 2 : 3; } // word.cpp:233
-
-// update_identity for one (oligo, key) (optimize.cpp:209-261)
-__device__ float identity(const OligoDev &o, const Planes &key, int use_taq)
-{
-	const uint32_t cnt = __popc((key.a & o.m.a) | (key.c & o.m.c) | (key.g & o.m.g) | (key.t & o.m.t));
-	float id = __fmul_rn((float)cnt, o.norm);
-	if(use_taq && nondegen(o.p1) && nondegen(o.p2)){
-		const uint32_t t1 = nibble_at(key, o.stop - 1), t2 = nibble_at(key, o.stop);
-		if(nondegen(t1) && nondegen(t2)){
-			const float corr = fminf(1.0f, c_taq_mama[16*(4*taq_idx(t2) + taq_idx(t1)) + (4*taq_idx(o.p2) + taq_idx(o.p1))]);
-			id = __fmul_rn(id, corr);
-		}
-	}
-	return id;
-}
-
-// Sequence::has_split (sequence.cpp:304-330) on the plane store: any EOS in [start, start+n)?
-__device__ bool has_split(const uint4 *__restrict__ planes, uint64_t base, int32_t start, int32_t n)
-{
-	int32_t pos = start;
-	const int32_t end = start + n;
-	while(pos < end){
-		const uint32_t b = (uint32_t)pos >> 5, sh = (uint32_t)pos & 31;
-		const uint4 v = planes[base + b];
-		uint32_t nz = (v.x | v.y | v.z | v.w) >> sh;
-		const int32_t span = min(32 - (int32_t)sh, end - pos);
-		const uint32_t want = (span == 32) ? 0xFFFFFFFFu : ((1u << span) - 1u);
-		if((nz & want) != want) return true;
-		pos += span;
-	}
-	return false;
-}
-
-// One lane per plus-strand DB entry i; it walks the later entries j of the same sequence
-// (sorted by WordMatch::loc, as assay.h:48-61) and, for every assay pair matched by both,
-// applies find_amplicon_match (pcr_assay.cpp:338-441) and the identity test.
-__global__ void k_pair(const DevEntry *__restrict__ db, uint32_t n, const uint32_t *__restrict__ n_touched_dev, uint32_t cap, const uint32_t *__restrict__ touched,
-	const uint32_t *__restrict__ seg_hi, const uint32_t *__restrict__ mask, uint32_t mask_words, const OligoDev *__restrict__ oligos, uint32_t n_pairs,
-	const uint4 *__restrict__ planes, const uint64_t *__restrict__ blk_off, const uint64_t *__restrict__ len,
-	const uint8_t *__restrict__ active, int32_t amp_min, int32_t amp_max, float ident_thr, int use_taq,
-	uint64_t *__restrict__ bits_fr, uint64_t *__restrict__ bits_rf, uint64_t bit_words, uint32_t *__restrict__ status)
-{
-	if(n_touched_dev) n = (*n_touched_dev)*cap;                                  // asynchronous passes
-	for(uint32_t t = blockIdx.x*blockDim.x + threadIdx.x;t < n;t += gridDim.x*blockDim.x){
-	uint32_t i;
-	if(!db_slot(t, n, cap, touched, seg_hi, i)) continue;
-	const DevEntry ei = db[i];
-	if(ei.strand != 1) continue;
-	if(!active[ei.seq]) continue;                                                // optimize.cpp:281
-	const uint32_t hi = seg_hi[ei.seq];
-	const int32_t L = (int32_t)len[ei.seq];
-	const uint64_t base = blk_off[ei.seq];
-	for(uint32_t j = i + 1;j < hi;++j){
-		const DevEntry ej = db[j];
-		if(ej.loc - ei.loc > amp_max + 128) break;   // beyond any admissible amplicon (slack: slots + end clamp)
-		if(ej.strand != 2) continue;
-		for(uint32_t w = 0;w < mask_words;++w){
-			// oligo o = 2*pair + {0:F, 1:R}; F bits are the even bits, R bits the odd bits
-			const uint32_t mi = mask[(size_t)i*mask_words + w], mj = mask[(size_t)j*mask_words + w];
-			// orientation FR: F matches plus entry i, R matches minus entry j
-			uint32_t fr = mi & (mj >> 1) & 0x55555555u;
-			// orientation RF: R matches plus entry i, F matches minus entry j
-			uint32_t rf = (mi >> 1) & mj & 0x55555555u;
-			uint32_t any = fr | rf;
-			while(any){
-				const uint32_t bit = __ffs(any) - 1;
-				any &= any - 1;
-				const uint32_t pair = (w*32 + bit) >> 1;
-				if(pair >= n_pairs) break;
-				const OligoDev F = oligos[2*pair], R = oligos[2*pair + 1];
-				for(int orient = 0;orient < 2;++orient){
-					if(!(((orient == 0) ? fr : rf) >> bit & 1u)) continue;
-					const OligoDev &P = (orient == 0) ? F : R;   // plus-role oligo
-					const OligoDev &M = (orient == 0) ? R : F;   // minus-role oligo
-					// pcr_assay.cpp:367-370 (WordMatch::template_loc3 / loc5, sequence.h:57-75)
-					if(ei.loc + P.stop >= ej.loc - M.stop) continue;
-					int32_t amp_start = ei.loc + P.start;
-					const int32_t amp_stop = min(ej.loc - M.start, L - 1);
-					int32_t amp_len = amp_stop - amp_start + 1;
-					if(amp_len < amp_min || amp_len > amp_max) continue;
-					if(amp_start < 0){ amp_len += amp_start; amp_start = 0; }
-					if(amp_len < 0 || amp_start + amp_len > L){ atomicOr(status, 1u); continue; }   // sequence.cpp:306 throw
-					if(has_split(planes, base, amp_start, amp_len)) continue;
-					const float f = identity(F, (orient == 0) ? ei.w : ej.w, use_taq);
-					const float r = identity(R, (orient == 0) ? ej.w : ei.w, use_taq);
-					if(__fsqrt_rn(__fmul_rn(f, r)) >= ident_thr){                // pcr_assay.cpp:572-576
-						uint64_t *dst = (orient == 0) ? bits_fr : bits_rf;
-						atomicOr((unsigned long long *)&dst[(size_t)pair*bit_words + (ei.seq >> 6)], 1ull << (ei.seq & 63));
-					}
-				}
-			}
-		}
-	}
-	}
-}
-
-// Local-search move evaluation (optimize_pcr.cpp, e.g. :77-93): the candidate amplicons are those of the
-// BASE pair (masks from k_match over {F, R}; geometry, has_split and the amplicon range from the base
-// oligos, exactly k_pair's sweep); for each variant of the edited oligo (`side`) only that oligo's
-// identity is re-evaluated (update_identity with the variant's own length and 3' bases), the other
-// side keeps the base oligo's.  bits_*[v][seq].
-__global__ void k_pair_moves(const DevEntry *__restrict__ db, uint32_t n, uint32_t cap, const uint32_t *__restrict__ touched,
-	const uint32_t *__restrict__ seg_hi, const uint32_t *__restrict__ mask, const OligoDev *__restrict__ base /* F, R */,
-	const OligoDev *__restrict__ variants, uint32_t n_variants, int side,
-	const uint4 *__restrict__ planes, const uint64_t *__restrict__ blk_off, const uint64_t *__restrict__ len,
-	const uint8_t *__restrict__ active, int32_t amp_min, int32_t amp_max, float ident_thr, int use_taq,
-	uint64_t *__restrict__ bits_fr, uint64_t *__restrict__ bits_rf, uint64_t bit_words, uint32_t *__restrict__ status)
-{
-	const uint32_t t = blockIdx.x*blockDim.x + threadIdx.x;
-	uint32_t i;
-	if(!db_slot(t, n, cap, touched, seg_hi, i)) return;
-	const DevEntry ei = db[i];
-	if(ei.strand != 1) return;
-	if(!active[ei.seq]) return;                                                  // optimize.cpp:281
-	const uint32_t hi = seg_hi[ei.seq];
-	const int32_t L = (int32_t)len[ei.seq];
-	const uint64_t blk_base = blk_off[ei.seq];
-	const OligoDev F = base[0], R = base[1];
-	for(uint32_t j = i + 1;j < hi;++j){
-		const DevEntry ej = db[j];
-		if(ej.loc - ei.loc > amp_max + 128) break;
-		if(ej.strand != 2) continue;
-		const uint32_t mi = mask[i], mj = mask[j];                               // bit 0 = F, bit 1 = R (one mask word)
-		const uint32_t fr = mi & (mj >> 1) & 1u, rf = (mi >> 1) & mj & 1u;
-		for(int orient = 0;orient < 2;++orient){
-			if(!((orient == 0) ? fr : rf)) continue;
-			const OligoDev &P = (orient == 0) ? F : R;   // plus-role oligo
-			const OligoDev &M = (orient == 0) ? R : F;   // minus-role oligo
-			if(ei.loc + P.stop >= ej.loc - M.stop) continue;                     // pcr_assay.cpp:367-370
-			int32_t amp_start = ei.loc + P.start;
-			const int32_t amp_stop = min(ej.loc - M.start, L - 1);
-			int32_t amp_len = amp_stop - amp_start + 1;
-			if(amp_len < amp_min || amp_len > amp_max) continue;
-			if(amp_start < 0){ amp_len += amp_start; amp_start = 0; }
-			if(amp_len < 0 || amp_start + amp_len > L){ atomicOr(status, 1u); continue; }   // sequence.cpp:306 throw
-			if(has_split(planes, blk_base, amp_start, amp_len)) continue;
-			// key matched by F / by R in this orientation
-			const Planes &key_f = (orient == 0) ? ei.w : ej.w;
-			const Planes &key_r = (orient == 0) ? ej.w : ei.w;
-			const float fixed = (side == 0) ? identity(R, key_r, use_taq) : identity(F, key_f, use_taq);
-			const Planes &key_v = (side == 0) ? key_f : key_r;
-			uint64_t *dst = (orient == 0) ? bits_fr : bits_rf;
-			for(uint32_t v = 0;v < n_variants;++v){
-				const float var = identity(variants[v], key_v, use_taq);
-				const float f = (side == 0) ? var : fixed, r = (side == 0) ? fixed : var;
-				if(__fsqrt_rn(__fmul_rn(f, r)) >= ident_thr)                     // pcr_assay.cpp:285-287
-					atomicOr((unsigned long long *)&dst[(size_t)v*bit_words + (ei.seq >> 6)], 1ull << (ei.seq & 63));
-			}
-		}
-	}
-}
-
-// The whole tail of a fused pass in ONE launch (k_touched + k_finalize + k_match + k_pair, for the common
-// case of 64-slot buckets and <= 128 oligos): one wave per SEQUENCE of the set -- a wave whose sequence
-// collected no hit leaves at once -- keeps the final-maximum hits, sorts and dedupes them (one key per lane),
-// materialises the sequence's DB entries (global, for later callers, and LDS), builds their oligo masks and
-// runs k_pair's sweep over them out of LDS.  The touched list is not built (ensure_touched() does it on
-// demand); the has_split range error goes to counters[1]; block 0 publishes the pass's counters.
-constexpr int POST_WAVES = 8;
-constexpr uint32_t POST_CAP = 64, POST_MASK_WORDS = 4;
-struct PostShared {
-	OligoDev ol[32*POST_MASK_WORDS];           // the pass's oligo table, staged once per workgroup
-	uint64_t keys[POST_WAVES][POST_CAP]; DevEntry ent[POST_WAVES][POST_CAP]; uint32_t msk[POST_WAVES][POST_CAP][POST_MASK_WORDS];
-};
-
-__global__ __launch_bounds__(64*POST_WAVES) void k_post(const Hit *__restrict__ hits, const uint32_t *__restrict__ seq_count,
-	const uint32_t *__restrict__ best, uint32_t ncand, const uint4 *__restrict__ planes, const uint64_t *__restrict__ blk_off,
-	const IrrDev *__restrict__ irr, const uint32_t *__restrict__ irr_off, DevEntry *__restrict__ db, uint32_t *__restrict__ seg_hi,
-	uint32_t *__restrict__ counters, uint32_t epoch, uint32_t n_seq,
-	const OligoDev *__restrict__ oligos, uint32_t n_pairs, uint32_t mask_words,
-	const uint64_t *__restrict__ len, const uint8_t *__restrict__ active, int32_t amp_min, int32_t amp_max, float ident_thr, int use_taq,
-	uint64_t *__restrict__ bits_fr, uint64_t *__restrict__ bits_rf, uint64_t bit_words, PassMail *pub_mail, uint32_t pub_seq)
-{
-	__shared__ PostShared sh;
-	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-	if(pub_mail && blockIdx.x == 0 && wave == 0){              // every scan of the pass is complete: its counters -> host mailbox
-		if(lane < 4) pub_mail->counters[lane] = (lane == 3) ? N_TOUCHED_UNKNOWN_DEV : counters[lane];
-		__threadfence_system();
-		__builtin_amdgcn_wave_barrier();
-		if(lane == 0) __hip_atomic_store((uint32_t *)&pub_mail->seq, pub_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-	}
-	const uint32_t seq = blockIdx.x*POST_WAVES + wave;
-	const uint32_t n = (seq < n_seq) ? min(seq_count[seq], POST_CAP) : 0u;
-	// a workgroup with at least one busy wave stages the oligo table (a chain of dependent scalar loads per
-	// oligo made the match loop the longest part of the wave's life)
-	if(__syncthreads_or((int)n)){
-		const uint32_t nw = 2*n_pairs*(uint32_t)(sizeof(OligoDev)/4);
-		for(uint32_t i = threadIdx.x;i < nw;i += 64*POST_WAVES) ((uint32_t *)sh.ol)[i] = ((const uint32_t *)oligos)[i];
-		__syncthreads();
-	}
-	if(n == 0) return;                                          // seg_hi[seq] stays 0 = empty
-	uint64_t *keys = sh.keys[wave];
-	DevEntry *ent = sh.ent[wave];
-	// ---- k_finalize: one key per lane
-	uint64_t k = ~0ull;
-	if(lane < n){
-		const Hit h = hits[(size_t)seq*POST_CAP + lane];
-		if(((epoch << 8) | h.cnt) == best[(size_t)seq*ncand + h.cand]) k = h.key;
-	}
-	keys[lane] = k;
-	wave_sync();
-	uint32_t np2 = 1; while(np2 < n) np2 <<= 1;                // sentinels beyond n are already in place: sort only the first np2 keys
-	for(uint32_t kk = 2;kk <= np2;kk <<= 1){
-		for(uint32_t j = kk >> 1;j > 0;j >>= 1){
-			const uint32_t l = lane ^ j;
-			if(l > lane && l < np2){
-				const uint64_t a = keys[lane], b = keys[l];
-				const bool up = ((lane & kk) == 0);
-				if((a > b) == up){ keys[lane] = b; keys[l] = a; }
-			}
-			wave_sync();
-		}
-	}
-	k = keys[lane];
-	const bool distinct = k != ~0ull && (lane == 0 || keys[lane - 1] != k);
-	const uint64_t dmask = __ballot(distinct);
-	const uint32_t run = (uint32_t)__builtin_popcountll(dmask);
-	const uint32_t rank = (uint32_t)__builtin_popcountll(dmask & ((1ull << lane) - 1ull));
-	if(lane == 0) seg_hi[seq] = seq*POST_CAP + run;
-	if(distinct){
-		DevEntry e;
-		materialise_entry(k, planes, blk_off, irr, irr_off, e);
-		db[(size_t)seq*POST_CAP + rank] = e;
-		ent[rank] = e;
-	}
-	wave_sync();
-	if(n_pairs == 0) return;
-	// ---- k_match: lane = entry, oligos walked with scalar operands
-	const uint32_t n_oligo = 2*n_pairs;
-	DevEntry me; me.w.a = me.w.c = me.w.g = me.w.t = 0; me.loc = 0; me.seq = seq; me.strand = 0; me.pad = 0;
-	if(lane < run) me = ent[lane];
-	for(uint32_t mw = 0;mw < mask_words;++mw){
-		uint32_t bits = 0;
-		const uint32_t o_end = min(n_oligo, (mw + 1)*32);
-#pragma unroll 4
-		for(uint32_t o = mw*32;o < o_end;++o){
-			const Planes m = sh.ol[o].m;
-			const uint32_t cnt = __popc((me.w.a & m.a) | (me.w.c & m.c) | (me.w.g & m.g) | (me.w.t & m.t));
-			bits |= (uint32_t)(cnt >= sh.ol[o].floor2) << (o & 31);
-		}
-		sh.msk[wave][lane][mw] = (lane < run) ? bits : 0u;
-	}
-	wave_sync();
-	// ---- k_pair: lane = plus-strand entry i, walks the later entries of the sequence
-	if(lane >= run || me.strand != 1 || !active[seq]) return;           // optimize.cpp:281
-	const int32_t L = (int32_t)len[seq];
-	const uint64_t base = blk_off[seq];
-	for(uint32_t j = lane + 1;j < run;++j){
-		const DevEntry ej = ent[j];
-		if(ej.loc - me.loc > amp_max + 128) break;
-		if(ej.strand != 2) continue;
-		for(uint32_t w = 0;w < mask_words;++w){
-			const uint32_t mi = sh.msk[wave][lane][w], mj = sh.msk[wave][j][w];
-			uint32_t fr = mi & (mj >> 1) & 0x55555555u;
-			uint32_t rf = (mi >> 1) & mj & 0x55555555u;
-			uint32_t any = fr | rf;
-			while(any){
-				const uint32_t bit = __ffs(any) - 1;
-				any &= any - 1;
-				const uint32_t pair = (w*32 + bit) >> 1;
-				if(pair >= n_pairs) break;
-				const OligoDev F = sh.ol[2*pair], R = sh.ol[2*pair + 1];
-				for(int orient = 0;orient < 2;++orient){
-					if(!(((orient == 0) ? fr : rf) >> bit & 1u)) continue;
-					const OligoDev &P = (orient == 0) ? F : R;   // plus-role oligo
-					const OligoDev &M = (orient == 0) ? R : F;   // minus-role oligo
-					if(me.loc + P.stop >= ej.loc - M.stop) continue;                       // pcr_assay.cpp:367-370
-					int32_t amp_start = me.loc + P.start;
-					const int32_t amp_stop = min(ej.loc - M.start, L - 1);
-					int32_t amp_len = amp_stop - amp_start + 1;
-					if(amp_len < amp_min || amp_len > amp_max) continue;
-					if(amp_start < 0){ amp_len += amp_start; amp_start = 0; }
-					if(amp_len < 0 || amp_start + amp_len > L){ atomicOr(&counters[1], 1u); continue; }   // sequence.cpp:306 throw
-					if(has_split(planes, base, amp_start, amp_len)) continue;
-					const float f = identity(F, (orient == 0) ? me.w : ej.w, use_taq);
-					const float r = identity(R, (orient == 0) ? ej.w : me.w, use_taq);
-					if(__fsqrt_rn(__fmul_rn(f, r)) >= ident_thr){                        // pcr_assay.cpp:572-576
-						uint64_t *dst = (orient == 0) ? bits_fr : bits_rf;
-						atomicOr((unsigned long long *)&dst[(size_t)pair*bit_words + (seq >> 6)], 1ull << (seq & 63));
-					}
-				}
-			}
-		}
-	}
-}
+#include "pcr_screen.inc"
 
 #include "pcr_sw.inc"
 #include "pcr_thermo.inc"
@@ -2160,415 +1815,4 @@ int64_t pcr_host_move_trials(const pcr_word128 *oligo, int move, double max_dege
 
 } // extern "C"
 
-// ------------------------------------------------------------------ Smith-Waterman entry points
-namespace {
-
-// SeqOverlap::pack_query_slots (seq_overlap.h:828-857): size() codes starting at start()
-int word_codes(const Planes &w, uint8_t *codes)
-{
-	const int len = pcrhost::planes_size(w), start = pcrhost::planes_start(w);
-	for(int k = 0;k < 32;++k) codes[k] = (k < len && start + k < 32) ? (uint8_t)pcrhost::planes_nibble(w, start + k) : 0;
-	return len;
-}
-
-// queries of pair p: 4p + {0: F, 1: (F), 2: R, 3: (R)} and the per-pair constants of background_match.cpp:20-42
-int upload_pair_queries(pcr_ctx *ctx, const pcr_pair *pairs, uint32_t n_pairs)
-{
-	std::vector<uint8_t> q((size_t)n_pairs*4*32), ql((size_t)n_pairs*4);
-	std::vector<BgPairDev> bp(n_pairs);
-	for(uint32_t p = 0;p < n_pairs;++p){
-		const Planes F = pcrhost::planes_of_word(pairs[p].f.w), R = pcrhost::planes_of_word(pairs[p].r.w);
-		const Planes o[4] = {F, pcrhost::planes_revcomp(F), R, pcrhost::planes_revcomp(R)};
-		uint8_t last[4][2];
-		for(int l = 0;l < 4;++l){
-			ql[(size_t)p*4 + l] = (uint8_t)word_codes(o[l], &q[((size_t)p*4 + l)*32]);
-			const int stop = pcrhost::planes_stop(o[l]);                          // Word::get_last_two, word.h:299
-			last[l][0] = (stop >= 1) ? (uint8_t)pcrhost::planes_nibble(o[l], stop - 1) : 0;
-			last[l][1] = (stop >= 0) ? (uint8_t)pcrhost::planes_nibble(o[l], stop) : 0;
-		}
-		BgPairDev b;
-		float f_norm = 2.0f*(unsigned)pcrhost::planes_size(F), r_norm = 2.0f*(unsigned)pcrhost::planes_size(R);   // PERFECT_MATCH_SCORE, assay.h:15
-		if(f_norm > 0.0f) f_norm = 1.0f/f_norm;
-		if(r_norm > 0.0f) r_norm = 1.0f/r_norm;
-		b.f_norm = f_norm; b.r_norm = r_norm;
-		b.fp1 = last[0][0]; b.fp2 = last[0][1]; b.fm1 = last[1][0]; b.fm2 = last[1][1];
-		b.rp1 = last[2][0]; b.rp2 = last[2][1]; b.rm1 = last[3][0]; b.rm2 = last[3][1];
-		bp[p] = b;
-	}
-	int rc;
-	if((rc = ctx->sw_q.ensure(q.size())) != PCR_OK) return rc;
-	if((rc = ctx->sw_qlen.ensure(ql.size())) != PCR_OK) return rc;
-	if((rc = ctx->bg_pairs.ensure(bp.size())) != PCR_OK) return rc;
-	HIP_TRY(hipMemcpyAsync(ctx->sw_q.p, q.data(), q.size(), hipMemcpyHostToDevice, ctx->stream));
-	HIP_TRY(hipMemcpyAsync(ctx->sw_qlen.p, ql.data(), ql.size(), hipMemcpyHostToDevice, ctx->stream));
-	HIP_TRY(hipMemcpyAsync(ctx->bg_pairs.p, bp.data(), bp.size()*sizeof(BgPairDev), hipMemcpyHostToDevice, ctx->stream));
-	HIP_TRY(hipStreamSynchronize(ctx->stream));
-	return PCR_OK;
-}
-
-int launch_sw(pcr_ctx *ctx, uint64_t n_jobs, const uint8_t *d_tcodes)
-{
-	if(n_jobs == 0) return PCR_OK;
-	if(n_jobs >= (uint64_t(1) << 31)){ g_err = "too many alignment jobs in one call"; return PCR_ERR_CAPACITY; }
-	int rc;
-	if((rc = ctx->sw_out.ensure(n_jobs)) != PCR_OK) return rc;
-	const unsigned jobs_per_block = SW_THREADS/32;
-	hipLaunchKernelGGL(k_sw, dim3((unsigned)((n_jobs + jobs_per_block - 1)/jobs_per_block)), dim3(SW_THREADS), 0, ctx->stream,
-		ctx->sw_jobs.p, (uint32_t)n_jobs, ctx->sw_q.p, ctx->sw_qlen.p, d_tcodes, ctx->sw_out.p);
-	HIP_TRY(hipGetLastError());
-	return PCR_OK;
-}
-
-} // namespace
-
-extern "C" {
-
-int pcr_sw_align_words(pcr_ctx *ctx, const pcr_word128 *queries, const pcr_word128 *templates, uint32_t n, pcr_sw_result *out)
-{
-	if(!ctx || (n && (!queries || !templates || !out))){ g_err = "pcr_sw_align_words: bad argument"; return PCR_ERR_ARG; }
-	if(n == 0) return PCR_OK;
-	HIP_TRY(hipSetDevice(ctx->device));
-	std::vector<uint8_t> q((size_t)n*32), ql(n), t((size_t)n*32);
-	std::vector<SwJob> jobs(n);
-	for(uint32_t i = 0;i < n;++i){
-		ql[i] = (uint8_t)word_codes(pcrhost::planes_of_word(queries[i].w), &q[(size_t)i*32]);
-		const int tl = word_codes(pcrhost::planes_of_word(templates[i].w), &t[(size_t)i*32]);
-		jobs[i].q = i; jobs[i].tlen = (uint32_t)tl; jobs[i].t_off = (uint64_t)i*32;
-	}
-	int rc;
-	if((rc = ctx->sw_q.ensure(q.size())) != PCR_OK) return rc;
-	if((rc = ctx->sw_qlen.ensure(n)) != PCR_OK) return rc;
-	if((rc = ctx->sw_t.ensure(t.size())) != PCR_OK) return rc;
-	if((rc = ctx->sw_jobs.ensure(n)) != PCR_OK) return rc;
-	HIP_TRY(hipMemcpyAsync(ctx->sw_q.p, q.data(), q.size(), hipMemcpyHostToDevice, ctx->stream));
-	HIP_TRY(hipMemcpyAsync(ctx->sw_qlen.p, ql.data(), n, hipMemcpyHostToDevice, ctx->stream));
-	HIP_TRY(hipMemcpyAsync(ctx->sw_t.p, t.data(), t.size(), hipMemcpyHostToDevice, ctx->stream));
-	HIP_TRY(hipMemcpyAsync(ctx->sw_jobs.p, jobs.data(), n*sizeof(SwJob), hipMemcpyHostToDevice, ctx->stream));
-	if((rc = launch_sw(ctx, n, ctx->sw_t.p)) != PCR_OK) return rc;
-	static_assert(sizeof(SwOut) == sizeof(pcr_sw_result), "result layout");
-	HIP_TRY(hipMemcpyAsync(out, ctx->sw_out.p, n*sizeof(SwOut), hipMemcpyDeviceToHost, ctx->stream));
-	HIP_TRY(hipStreamSynchronize(ctx->stream));
-	return PCR_OK;
-}
-
-int pcr_background_match(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_pairs, const pcr_background_args *args,
-	uint64_t *bits)
-{
-	if(!ctx || !args || (n_pairs && (!pairs || !bits))){ g_err = "pcr_background_match: bad argument"; return PCR_ERR_ARG; }
-	DRAIN(ctx);
-	HIP_TRY(hipSetDevice(ctx->device));
-	SeqSet &S = ctx->sets[which];
-	if(!S.have_db){ g_err = "pcr_background_match: no word DB (call pcr_select_words first)"; return PCR_ERR_STATE; }
-	{ const int erc = ensure_touched(ctx, S); if(erc != PCR_OK) return erc; }
-	const uint64_t words = (S.n + 63)/64;
-	const size_t total = (size_t)n_pairs*words;
-	if(total) memset(bits, 0, total*sizeof(uint64_t));
-	if(S.n_entries == 0 || n_pairs == 0) return PCR_OK;
-	int rc;
-	// match_words of every oligo against the DB, as collect_candidates (pcr_assay.cpp:31-32)
-	const float thr2 = args->collect_threshold*args->collect_threshold;
-	std::vector<OligoDev> ol(2*(size_t)n_pairs);
-	for(uint32_t i = 0;i < n_pairs;++i){ fill_oligo(ol[2*i], pairs[i].f.w, thr2); fill_oligo(ol[2*i + 1], pairs[i].r.w, thr2); }
-	if((rc = ctx->oligos.ensure(ol.size())) != PCR_OK) return rc;
-	HIP_TRY(hipMemcpyAsync(ctx->oligos.p, ol.data(), ol.size()*sizeof(OligoDev), hipMemcpyHostToDevice, ctx->stream));
-	HIP_TRY(hipStreamSynchronize(ctx->stream));
-	if((rc = upload_pair_queries(ctx, pairs, n_pairs)) != PCR_OK) return rc;
-	const uint32_t mask_words = (2*n_pairs + 31)/32;
-	if((rc = ctx->mask.ensure((size_t)S.n_slots*mask_words)) != PCR_OK) return rc;
-	if((rc = ctx->status.ensure(1)) != PCR_OK) return rc;
-	if((rc = ctx->counters.ensure(4)) != PCR_OK) return rc;
-	if((rc = ctx->bits_fr.ensure(total)) != PCR_OK) return rc;
-	const unsigned threads = 128;
-	const uint32_t n_db = S.n_touched*S.db_cap;
-	const unsigned grid = (n_db + threads - 1)/threads;
-	hipLaunchKernelGGL(k_match, dim3((S.n_touched + MATCH_WAVES - 1)/MATCH_WAVES), dim3(64*MATCH_WAVES), 0, ctx->stream, S.db.p, S.n_touched, (const uint32_t *)nullptr, S.db_cap,
-		S.touched.p, S.d_seg_hi, ctx->oligos.p, 2*n_pairs, mask_words, ctx->mask.p, (uint32_t *)nullptr, (const uint32_t *)nullptr, (pcr_ctx::Mail *)nullptr, 0u);
-	HIP_TRY(hipGetLastError());
-	uint32_t n_amp = 0, status = 0;
-	for(int attempt = 0;;++attempt){
-		if((rc = ctx->amp_recs.ensure(ctx->amp_cap)) != PCR_OK) return rc;
-		HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, 4*sizeof(uint32_t), ctx->stream));
-		HIP_TRY(hipMemsetAsync(ctx->status.p, 0, sizeof(uint32_t), ctx->stream));
-		hipLaunchKernelGGL(k_pair_emit, dim3(grid), dim3(threads), 0, ctx->stream, S.db.p, n_db, S.db_cap, S.touched.p, S.d_seg_hi, ctx->mask.p, mask_words,
-			ctx->oligos.p, n_pairs, S.planes.p, S.d_blk_off.p, S.d_len.p, S.d_active.p, args->amp_min, args->amp_max,
-			ctx->amp_recs.p, (uint32_t)ctx->amp_cap, ctx->counters.p, ctx->status.p);
-		HIP_TRY(hipGetLastError());
-		HIP_TRY(hipMemcpyAsync(&n_amp, ctx->counters.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-		HIP_TRY(hipMemcpyAsync(&status, ctx->status.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-		HIP_TRY(hipStreamSynchronize(ctx->stream));
-		if(n_amp <= ctx->amp_cap) break;
-		if(attempt >= 4 || n_amp > (1u << 29)){ g_err = "pcr_background_match: candidate amplicon list does not fit"; return PCR_ERR_CAPACITY; }
-		ctx->amp_cap = (size_t)n_amp + (n_amp >> 3);
-	}
-	if(status & 1u){ g_err = "Sequence::has_split: range is out of bounds"; return PCR_ERR_RANGE; }
-	if(n_amp == 0) return PCR_OK;
-	if((rc = ctx->entry_codes.ensure((size_t)S.n_slots*32)) != PCR_OK) return rc;
-	if((rc = ctx->entry_lens.ensure(S.n_slots)) != PCR_OK) return rc;
-	if((rc = ctx->sw_jobs.ensure((size_t)n_amp*4)) != PCR_OK) return rc;
-	hipLaunchKernelGGL(k_entry_codes, dim3((unsigned)(((size_t)n_db*32 + 255)/256)), dim3(256), 0, ctx->stream, S.db.p, n_db, S.db_cap, S.touched.p, S.d_seg_hi, ctx->entry_codes.p, ctx->entry_lens.p);
-	HIP_TRY(hipGetLastError());
-	hipLaunchKernelGGL(k_bg_jobs, dim3((n_amp*4 + 255)/256), dim3(256), 0, ctx->stream, ctx->amp_recs.p, n_amp, ctx->entry_lens.p, ctx->sw_jobs.p);
-	HIP_TRY(hipGetLastError());
-	if((rc = launch_sw(ctx, (uint64_t)n_amp*4, ctx->entry_codes.p)) != PCR_OK) return rc;
-	HIP_TRY(hipMemsetAsync(ctx->bits_fr.p, 0, total*sizeof(uint64_t), ctx->stream));
-	hipLaunchKernelGGL(k_bg_score, dim3((n_amp + 255)/256), dim3(256), 0, ctx->stream, ctx->amp_recs.p, n_amp, ctx->sw_out.p, ctx->bg_pairs.p,
-		args->background_threshold, args->use_taq_mama, ctx->bits_fr.p, words);
-	HIP_TRY(hipGetLastError());
-	HIP_TRY(hipMemcpyAsync(bits, ctx->bits_fr.p, total*sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-	HIP_TRY(hipStreamSynchronize(ctx->stream));
-	return PCR_OK;
-}
-
-int pcr_multiplex_match(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_pairs, float background_threshold,
-	int use_taq_mama, uint64_t *bits)
-{
-	if(!ctx || (n_pairs && (!pairs || !bits))){ g_err = "pcr_multiplex_match: bad argument"; return PCR_ERR_ARG; }
-	DRAIN(ctx);
-	HIP_TRY(hipSetDevice(ctx->device));
-	SeqSet &S = ctx->sets[which];
-	const uint64_t words = (S.n + 63)/64;
-	const size_t total = (size_t)n_pairs*words;
-	if(total) memset(bits, 0, total*sizeof(uint64_t));
-	if(S.n == 0 || n_pairs == 0) return PCR_OK;
-	int rc;
-	std::vector<uint64_t> code_off(S.n);
-	uint64_t tot = 0;
-	for(uint32_t s = 0;s < S.n;++s){
-		if(S.len[s] > 32767){ g_err = "pcr_multiplex_match: template longer than 32767 bases (SeqOverlap's int16 coordinate range)"; return PCR_ERR_CAPACITY; }
-		code_off[s] = tot; tot += S.len[s];
-	}
-	if(!S.have_codes){
-		if((rc = S.codes.ensure(tot + 64)) != PCR_OK) return rc;
-		if((rc = S.d_code_off.ensure(S.n)) != PCR_OK) return rc;
-		HIP_TRY(hipMemcpyAsync(S.d_code_off.p, code_off.data(), S.n*sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
-		HIP_TRY(hipStreamSynchronize(ctx->stream));
-		hipLaunchKernelGGL(k_seq_codes, dim3(8, S.n), dim3(256), 0, ctx->stream, S.nib.p, S.d_blk_off.p, S.d_len.p, S.d_code_off.p, S.n, S.codes.p);
-		HIP_TRY(hipGetLastError());
-		S.have_codes = true;
-	}
-	if((rc = upload_pair_queries(ctx, pairs, n_pairs)) != PCR_OK) return rc;
-	const uint64_t n_jobs = (uint64_t)n_pairs*S.n*4;
-	if((rc = ctx->sw_jobs.ensure(n_jobs)) != PCR_OK) return rc;
-	if((rc = ctx->bits_fr.ensure(total)) != PCR_OK) return rc;
-	hipLaunchKernelGGL(k_mx_jobs, dim3((unsigned)((n_jobs + 255)/256)), dim3(256), 0, ctx->stream, n_pairs, S.n, S.d_len.p, S.d_code_off.p, ctx->sw_jobs.p);
-	HIP_TRY(hipGetLastError());
-	if((rc = launch_sw(ctx, n_jobs, S.codes.p)) != PCR_OK) return rc;
-	HIP_TRY(hipMemsetAsync(ctx->bits_fr.p, 0, total*sizeof(uint64_t), ctx->stream));
-	hipLaunchKernelGGL(k_mx_score, dim3((unsigned)(((uint64_t)n_pairs*S.n + 255)/256)), dim3(256), 0, ctx->stream, n_pairs, S.n, ctx->sw_out.p,
-		ctx->bg_pairs.p, background_threshold, use_taq_mama, ctx->bits_fr.p, words);
-	HIP_TRY(hipGetLastError());
-	HIP_TRY(hipMemcpyAsync(bits, ctx->bits_fr.p, total*sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-	HIP_TRY(hipStreamSynchronize(ctx->stream));
-	return PCR_OK;
-}
-
-} // extern "C"
-
-// ------------------------------------------------------------------ thermodynamics entry points
-namespace {
-
-// NucCruc::update_dp_param (nuc_cruc.cpp:191-342): the integer dG table of the alignment DP at
-// 37 C for a given salt.  Float arithmetic in the reference's order; log() is the float overload.
-void build_dg_table(float na, int *dg /* [49*49] */)
-{
-	using namespace thermo;
-	auto scale = [](float x){ return (int)(x*10000.0f); };                       // NC_SCORE_SCALE, nuc_cruc.h:235
-	const float sc = PCR_SALT*logf(na);
-	const float loop_sc = sc*PCR_SUPP_SALT[0], bulge_sc = sc*PCR_SUPP_SALT[1];
-	const float match_sc = sc*PCR_SUPP_SALT[2], mismatch_sc = sc*PCR_SUPP_SALT[3];
-	for(int i = 0;i < 49*49;++i) dg[i] = scale(PCR_NN_H[i] - TARGET_T*(PCR_NN_S[i] + sc));
-	for(int i = bA;i <= bI;++i) for(int j = bA;j <= bI;++j){
-		const int curr = i*NB + j;
-		for(int k = bA;k <= bI;++k){
-			const int prev1 = k*NB + bGAP, prev2 = bGAP*NB + k;
-			int v;
-			if(PCR_WC[curr]){
-				if(curr == pAT || curr == pTA) v = scale(PCR_SUPP[4] - TARGET_T*(PCR_SUPP[5] + match_sc));
-				else if(curr == pGC || curr == pCG) v = scale(PCR_SUPP[6] - TARGET_T*(PCR_SUPP[7] + match_sc));
-				else v = scale(PCR_SUPP[8] - TARGET_T*(PCR_SUPP[9] + match_sc));
-			}
-			else v = scale(PCR_SUPP[10] - TARGET_T*(PCR_SUPP[11] + mismatch_sc));
-			v = std::max(0, v);
-			dg[curr*49 + prev1] = dg[prev1*49 + curr] = dg[curr*49 + prev2] = dg[prev2*49 + curr] = v;
-		}
-		for(int k = bA;k <= bI;++k) for(int l = bA;l <= bI;++l){
-			const int prev = k*NB + l;
-			if(!PCR_WC[curr] && !PCR_WC[prev]) dg[curr*49 + prev] = std::max(0, scale(PCR_SUPP[0] - TARGET_T*(PCR_SUPP[1] + loop_sc)));
-		}
-	}
-	for(int i = bA;i <= bI;++i) for(int j = bA;j <= bI;++j){
-		const int v = std::max(0, scale(PCR_SUPP[2] - TARGET_T*(PCR_SUPP[3] + bulge_sc)));
-		dg[(i*NB + bGAP)*49 + (j*NB + bGAP)] = v;
-		dg[(bGAP*NB + i)*49 + (bGAP*NB + j)] = v;
-	}
-}
-
-bool job_set(unsigned char *dst, unsigned char &len, const std::vector<uint8_t> &s)
-{
-	if(s.empty() || s.size() > (size_t)thermo::MAXL) return false;
-	for(size_t i = 0;i < s.size();++i){ if(s[i] > 3) return false; dst[i] = s[i]; }
-	len = (unsigned char)s.size();
-	return true;
-}
-
-int run_thermo_jobs(pcr_ctx *ctx, const std::vector<thermo::Job> &jobs, float salt, std::vector<thermo::JobOut> &out)
-{
-	out.resize(jobs.size());
-	if(jobs.empty()) return PCR_OK;
-	if(!(salt >= 1.0e-6f && salt <= 1.0f)){ g_err = "thermo: salt outside [1e-6, 1] (NucCruc::salt, nuc_cruc.h:780-788)"; return PCR_ERR_ARG; }
-	int dg[49*49];
-	build_dg_table(salt, dg);
-	const size_t n = jobs.size();
-	const size_t n_blocks = (n + thermo::THERMO_THREADS - 1)/thermo::THERMO_THREADS;
-	// bound the scratch slab: run the jobs in chunks of <= 4096 blocks (~3.4 GB of DP matrices)
-	const size_t max_blocks = 4096;
-	int rc;
-	if((rc = ctx->th_dg.ensure(49*49)) != PCR_OK) return rc;
-	if((rc = ctx->th_jobs.ensure(n)) != PCR_OK) return rc;
-	if((rc = ctx->th_out.ensure(n)) != PCR_OK) return rc;
-	const size_t blk = std::min(n_blocks, max_blocks);
-	if((rc = ctx->th_scratch_i.ensure(blk*3*thermo::NCELL*thermo::WAVE)) != PCR_OK) return rc;
-	if((rc = ctx->th_scratch_s.ensure(blk*thermo::NCELL*thermo::WAVE)) != PCR_OK) return rc;
-	HIP_TRY(hipMemcpyAsync(ctx->th_dg.p, dg, sizeof(dg), hipMemcpyHostToDevice, ctx->stream));
-	HIP_TRY(hipMemcpyAsync(ctx->th_jobs.p, jobs.data(), n*sizeof(thermo::Job), hipMemcpyHostToDevice, ctx->stream));
-	const float log_na = logf(salt);
-	for(size_t b0 = 0;b0 < n_blocks;b0 += max_blocks){
-		const size_t nb = std::min(max_blocks, n_blocks - b0);
-		const size_t j0 = b0*thermo::THERMO_THREADS;
-		const unsigned nj = (unsigned)std::min<size_t>(n - j0, nb*thermo::THERMO_THREADS);
-		hipLaunchKernelGGL(thermo::k_thermo, dim3((unsigned)nb), dim3(thermo::THERMO_THREADS), 0, ctx->stream, ctx->th_jobs.p + j0, nj,
-			ctx->th_dg.p, log_na, ctx->th_scratch_i.p, ctx->th_scratch_s.p, ctx->th_out.p + j0);
-		HIP_TRY(hipGetLastError());
-	}
-	HIP_TRY(hipMemcpyAsync(out.data(), ctx->th_out.p, n*sizeof(thermo::JobOut), hipMemcpyDeviceToHost, ctx->stream));
-	HIP_TRY(hipStreamSynchronize(ctx->stream));
-	for(size_t i = 0;i < n;++i){ if(out[i].status & 1u){ g_err = "thermo: internal trace-back error"; return PCR_ERR_RANGE; } }
-	return PCR_OK;
-}
-
-const size_t MAX_EXPANSIONS = 1u << 16;
-
-} // namespace
-
-extern "C" {
-
-int pcr_thermo(pcr_ctx *ctx, const pcr_word128 *oligos, uint32_t n, int check_homo_dimer, const pcr_thermo_args *args,
-	pcr_thermo_result *out)
-{
-	if(!ctx || !args || (n && (!oligos || !out))){ g_err = "pcr_thermo: bad argument"; return PCR_ERR_ARG; }
-	HIP_TRY(hipSetDevice(ctx->device));
-	std::vector<thermo::Job> jobs;
-	std::vector<uint32_t> first(n + 1, 0);
-	for(uint32_t i = 0;i < n;++i){
-		first[i] = (uint32_t)jobs.size();
-		const Planes w = pcrhost::planes_of_word(oligos[i].w);
-		std::vector<std::vector<uint8_t> > ex;
-		if(!pcrhost::expand_oligo(w, ex, MAX_EXPANSIONS)){ g_err = "pcr_thermo: more than 65536 expansions of one oligo"; return PCR_ERR_CAPACITY; }
-		if(ex.empty()){ g_err = "pcr_thermo: empty oligo"; return PCR_ERR_ARG; }
-		const double degen = pcrhost::planes_degeneracy(w);
-		const float strand = (float)(args->primer_strand/degen);                 // valid_pcr.cpp:13
-		for(const std::vector<uint8_t> &s : ex){
-			thermo::Job j; memset(&j, 0, sizeof(j));
-			if(!job_set(j.q, j.qlen, s)){ g_err = "pcr_thermo: oligo is empty, longer than 32 or holds a non-base slot (NucCruc::set_query throws)"; return PCR_ERR_ARG; }
-			j.mode = 0; j.check_homo = check_homo_dimer ? 1 : 0; j.log_strand = logf(strand);
-			jobs.push_back(j);
-		}
-	}
-	first[n] = (uint32_t)jobs.size();
-	std::vector<thermo::JobOut> res;
-	int rc = run_thermo_jobs(ctx, jobs, args->salt, res);
-	if(rc != PCR_OK) return rc;
-	for(uint32_t i = 0;i < n;++i){
-		pcr_thermo_result r; memset(&r, 0, sizeof(r));
-		r.n_expansions = first[i + 1] - first[i];
-		r.valid = 1;
-		for(uint32_t k = first[i];k < first[i + 1];++k){
-			const thermo::JobOut &o = res[k];
-			if(o.tm_pm < args->tm_min || o.tm_pm > args->tm_max) r.valid = 0;     // valid_pcr.cpp:19-23
-			if(o.tm_hairpin > args->max_hairpin) r.valid = 0;                     // :27-31
-			if(check_homo_dimer && o.tm_dimer > args->max_dimer) r.valid = 0;     // :34-41
-		}
-		if(r.n_expansions){
-			const thermo::JobOut &o = res[first[i]];
-			r.tm = o.tm_pm; r.dH = o.dH_pm; r.dS = o.dS_pm; r.hairpin_tm = o.tm_hairpin; r.homodimer_tm = o.tm_dimer;
-		}
-		out[i] = r;
-	}
-	return PCR_OK;
-}
-
-int pcr_dimer(pcr_ctx *ctx, const pcr_pair *pairs, uint32_t n, const pcr_thermo_args *args, float *max_tm)
-{
-	if(!ctx || !args || (n && (!pairs || !max_tm))){ g_err = "pcr_dimer: bad argument"; return PCR_ERR_ARG; }
-	HIP_TRY(hipSetDevice(ctx->device));
-	std::vector<thermo::Job> jobs;
-	std::vector<uint32_t> first(n + 1, 0);
-	for(uint32_t i = 0;i < n;++i){
-		first[i] = (uint32_t)jobs.size();
-		const Planes F = pcrhost::planes_of_word(pairs[i].f.w), R = pcrhost::planes_of_word(pairs[i].r.w);
-		std::vector<std::vector<uint8_t> > ef, er;
-		if(!pcrhost::expand_oligo(F, ef, MAX_EXPANSIONS) || !pcrhost::expand_oligo(R, er, MAX_EXPANSIONS) || ef.size()*er.size() > MAX_EXPANSIONS){
-			g_err = "pcr_dimer: too many expansions"; return PCR_ERR_CAPACITY;
-		}
-		const float ca = (float)(args->primer_strand/pcrhost::planes_degeneracy(F));   // pcr_assay.cpp:244
-		const float cb = (float)(args->primer_strand/pcrhost::planes_degeneracy(R));
-		const float strand = (ca > cb) ? ca - 0.5f*cb : cb - 0.5f*ca;             // nuc_cruc.h:832-837
-		for(const std::vector<uint8_t> &f : ef) for(const std::vector<uint8_t> &r : er){
-			thermo::Job j; memset(&j, 0, sizeof(j));
-			if(!job_set(j.q, j.qlen, f) || !job_set(j.t, j.tlen, r)){ g_err = "pcr_dimer: bad oligo"; return PCR_ERR_ARG; }
-			j.mode = 1; j.log_strand = logf(strand);
-			jobs.push_back(j);
-		}
-	}
-	first[n] = (uint32_t)jobs.size();
-	std::vector<thermo::JobOut> res;
-	int rc = run_thermo_jobs(ctx, jobs, args->salt, res);
-	if(rc != PCR_OK) return rc;
-	for(uint32_t i = 0;i < n;++i){
-		float m = 0.0f;
-		for(uint32_t k = first[i];k < first[i + 1];++k) m = std::max(m, res[k].tm_dimer);   // :262
-		max_tm[i] = m;
-	}
-	return PCR_OK;
-}
-
-int pcr_multiplex_compatible(pcr_ctx *ctx, const pcr_pair *a, const pcr_pair *b, uint32_t n, const pcr_thermo_args *args, uint8_t *ok)
-{
-	if(!ctx || !args || (n && (!a || !b || !ok))){ g_err = "pcr_multiplex_compatible: bad argument"; return PCR_ERR_ARG; }
-	HIP_TRY(hipSetDevice(ctx->device));
-	std::vector<thermo::Job> jobs;
-	std::vector<uint32_t> first(n + 1, 0);
-	const float log_strand = logf(args->primer_strand);                          // pcr_assay.cpp:819-821
-	for(uint32_t i = 0;i < n;++i){
-		first[i] = (uint32_t)jobs.size();
-		const uint64_t *qa[2] = {a[i].f.w, a[i].r.w}, *sb[2] = {b[i].f.w, b[i].r.w};
-		for(int qo = 0;qo < 2;++qo){
-			std::vector<std::vector<uint8_t> > eq;
-			if(!pcrhost::expand_oligo(pcrhost::planes_of_word(qa[qo]), eq, MAX_EXPANSIONS)){ g_err = "too many expansions"; return PCR_ERR_CAPACITY; }
-			for(int so = 0;so < 2;++so){
-				std::vector<std::vector<uint8_t> > es;
-				if(!pcrhost::expand_oligo(pcrhost::planes_of_word(sb[so]), es, MAX_EXPANSIONS) || eq.size()*es.size() > MAX_EXPANSIONS){
-					g_err = "too many expansions"; return PCR_ERR_CAPACITY;
-				}
-				for(const std::vector<uint8_t> &q : eq) for(const std::vector<uint8_t> &s : es){
-					thermo::Job j; memset(&j, 0, sizeof(j));
-					if(!job_set(j.q, j.qlen, q) || !job_set(j.t, j.tlen, s)){ g_err = "pcr_multiplex_compatible: bad oligo"; return PCR_ERR_ARG; }
-					j.mode = 1; j.log_strand = log_strand;
-					jobs.push_back(j);
-				}
-			}
-		}
-	}
-	first[n] = (uint32_t)jobs.size();
-	std::vector<thermo::JobOut> res;
-	int rc = run_thermo_jobs(ctx, jobs, args->salt, res);
-	if(rc != PCR_OK) return rc;
-	for(uint32_t i = 0;i < n;++i){
-		uint8_t good = 1;
-		for(uint32_t k = first[i];k < first[i + 1];++k){ if(res[k].tm_dimer >= args->max_dimer) good = 0; }   // :841
-		ok[i] = good;
-	}
-	return PCR_OK;
-}
-
-} // extern "C"
+#include "pcr_entry_sw_thermo.inc"
