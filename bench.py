@@ -67,8 +67,8 @@ def cpu_baseline(wl, thr_t, mult, budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="C2")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the target count (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -192,7 +192,7 @@ def main():
     scr.synchronize()
     drain_works()
     torch.cuda.synchronize()
-    scr.profile(True)
+    scr.profile(4)        # HIP events bracket the scan of every 4th pass: an event between two kernels costs a ~6 us queue bubble
     scr.profile_read(reset=True)
     if use_dist:
         dist.barrier()

@@ -160,8 +160,9 @@ uint32_t pcr_num_sequences(pcr_ctx *ctx, pcr_set which);
 uint64_t pcr_bitset_words(pcr_ctx *ctx, pcr_set which);   /* ceil(n/64) */
 
 /* Measurement hooks (bench.py): when enabled, the dominant kernel of pcr_select_words (the
- * oligo x window match scan) is bracketed by HIP events on the handle's stream.
- * pcr_profile_read: total milliseconds and number of launches since the last reset. */
+ * oligo x window match scan) is bracketed by HIP events on the handle's stream.  on = 1: every pass;
+ * on = n > 1: every n-th pass (an event packet between two kernels costs a ~6 us queue bubble).
+ * pcr_profile_read: total milliseconds and number of bracketed launches since the last reset. */
 int pcr_profile_enable(pcr_ctx *ctx, int on);
 int pcr_profile_read(pcr_ctx *ctx, double *scan_ms, uint64_t *scan_launches, int reset);
 

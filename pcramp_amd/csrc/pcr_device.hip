@@ -610,7 +610,8 @@ struct pcr_ctx {
 	// ring of host-mapped staging buffers: a slot is rewritten only after the k_stage that read it has run,
 	// so the host can prepare the next pass while the previous one is still on the GPU
 	static constexpr int STAGE_RING = 4;
-	struct StageSlot { uint8_t *host = nullptr, *dev = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool busy = false; };
+	struct StageSlot { uint8_t *host = nullptr, *dev = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool busy = false;
+	                   uint32_t guard_seq = 0; /* != 0: free once the pass with this mailbox sequence number has published */ };
 	StageSlot stage[STAGE_RING]; int stage_next = 0;
 	typedef PassMail Mail;
 	static constexpr uint32_t MAIL_RING = 8;
@@ -629,7 +630,7 @@ struct pcr_ctx {
 	// host-side phase timers (PCRAMP_TIMING=1: printed by pcr_destroy)
 	bool timing = false; double t_host[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint64_t n_timed = 0;
 	// profiling
-	bool prof = false;
+	bool prof = false; uint32_t prof_stride = 1, prof_pass = 0;   // events bracket the scan of every prof_stride-th pass
 	std::vector<std::pair<hipEvent_t, hipEvent_t> > prof_events;
 	double prof_ms = 0.0; uint64_t prof_launches = 0;
 };
@@ -724,6 +725,24 @@ __global__ void k_stage(const uint4 *__restrict__ src, uint4 *__restrict__ dst, 
 	for(uint32_t k = i;k < n2;k += stride) z2[k] = zero;
 }
 
+// Has the pass with mailbox sequence number `seq` published?  Publications happen in stream order and slot
+// seq % MAIL_RING is reused by seq + MAIL_RING, ...: any value of that slot at or beyond seq means yes.
+int wait_published(pcr_ctx *ctx, uint32_t seq)
+{
+	const PassMail *const slot = ctx->mail + (seq % pcr_ctx::MAIL_RING);
+	uint64_t spins = 0;
+	while(true){
+		const uint32_t v = __atomic_load_n((const uint32_t *)&slot->seq, __ATOMIC_ACQUIRE);
+		if(v >= seq && (v - seq) % pcr_ctx::MAIL_RING == 0) return PCR_OK;
+		__builtin_ia32_pause();
+		if((++spins & 0x3FFF) == 0){
+			const hipError_t e = hipStreamQuery(ctx->stream);
+			if(e == hipSuccess) return PCR_OK;                       // stream idle: whatever used the slot is over (the pass may have failed before publishing)
+			if(e != hipErrorNotReady){ g_err = std::string("device pass failed: ") + hipGetErrorString(e); return PCR_ERR_DEVICE; }
+		}
+	}
+}
+
 struct Stager {
 	pcr_ctx *ctx; size_t used = 0;
 	explicit Stager(pcr_ctx *c) : ctx(c) {}
@@ -733,6 +752,7 @@ struct Stager {
 		slot = &ctx->stage[ctx->stage_next];
 		ctx->stage_next = (ctx->stage_next + 1) % pcr_ctx::STAGE_RING;
 		if(slot->busy){ HIP_TRY(hipEventSynchronize(slot->done)); slot->busy = false; }
+		if(slot->guard_seq){ const int grc = wait_published(ctx, slot->guard_seq); if(grc != PCR_OK) return grc; slot->guard_seq = 0; }
 		if(bytes > slot->cap){
 			if(slot->host){ (void)hipHostFree(slot->host); slot->host = nullptr; slot->cap = 0; }
 			const size_t want = std::max<size_t>(bytes*2, 1 << 16);
@@ -756,7 +776,7 @@ struct Stager {
 	}
 	// z0/z1: device regions to clear in the same launch (16-byte aligned, sizes rounded UP to 16 bytes: the
 	// caller's buffers must be allocated with that slack)
-	int ship(void *z0 = nullptr, size_t bytes0 = 0, void *z1 = nullptr, size_t bytes1 = 0, void *z2 = nullptr, size_t bytes2 = 0)
+	int ship(void *z0 = nullptr, size_t bytes0 = 0, void *z1 = nullptr, size_t bytes1 = 0, void *z2 = nullptr, size_t bytes2 = 0, uint32_t guard_seq = 0)
 	{
 		const uint32_t n16 = (uint32_t)((used + 15)/16), n0 = (uint32_t)((bytes0 + 15)/16), n1 = (uint32_t)((bytes1 + 15)/16), n2 = (uint32_t)((bytes2 + 15)/16);
 		const uint32_t most = std::max(std::max(n16, n2), std::max(n0, n1));
@@ -766,8 +786,14 @@ struct Stager {
 				(uint4 *)z0, n0, (uint4 *)z1, n1, (uint4 *)z2, n2);
 			HIP_TRY(hipGetLastError());
 		}
-		HIP_TRY(hipEventRecord(slot->done, ctx->stream));
-		slot->busy = true;
+		// The slot may be rewritten once k_stage has run.  A pass publishes its counters after that (mailbox), so
+		// its sequence number is the guard; other callers record an event (an event packet between two kernels
+		// costs a ~5 us queue bubble, which is why passes avoid it).
+		if(guard_seq) slot->guard_seq = guard_seq;
+		else{
+			HIP_TRY(hipEventRecord(slot->done, ctx->stream));
+			slot->busy = true;
+		}
 		return PCR_OK;
 	}
 };
@@ -1350,9 +1376,9 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 		if(fuse){
 			fa->d_oligos = st.put(ol.data(), ol.size());
 			fa->staged = true;
-			if((rc = st.ship(S.ctrl.p, (8 + 2*(size_t)S.n)*sizeof(uint32_t), fa->d_fr, bits_bytes, fa->d_rf, bits_bytes)) != PCR_OK) return rc;
+			if((rc = st.ship(S.ctrl.p, (8 + 2*(size_t)S.n)*sizeof(uint32_t), fa->d_fr, bits_bytes, fa->d_rf, bits_bytes, ctx->mail_seq + 1)) != PCR_OK) return rc;
 		}
-		else if((rc = st.ship(S.ctrl.p, (8 + 2*(size_t)S.n)*sizeof(uint32_t))) != PCR_OK) return rc;
+		else if((rc = st.ship(S.ctrl.p, (8 + 2*(size_t)S.n)*sizeof(uint32_t), nullptr, 0, nullptr, 0, ctx->mail_seq + 1)) != PCR_OK) return rc;
 	}
 
 	timer.next(2);
@@ -1377,7 +1403,8 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 		bool irr_fused = false;                           // scanned by extra workgroups of k_seed
 		if(S.n_tiles){
 			hipEvent_t e0 = nullptr, e1 = nullptr;
-			if(ctx->prof){
+			const bool timed = ctx->prof && (ctx->prof_pass++ % ctx->prof_stride) == 0;   // an event between two kernels costs a ~6 us queue bubble
+			if(timed){
 				HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
 				HIP_TRY(hipEventRecord(e0, ctx->stream));
 			}
@@ -1424,7 +1451,7 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 						S.n_degen_tiles, d_map_seedset)) != PCR_OK) return rc;
 				}
 			}
-			if(ctx->prof){
+			if(timed){
 				HIP_TRY(hipEventRecord(e1, ctx->stream));
 				ctx->prof_events.push_back(std::make_pair(e0, e1));
 			}
@@ -1703,6 +1730,7 @@ int pcr_profile_enable(pcr_ctx *ctx, int on)
 {
 	if(!ctx){ g_err = "null ctx"; return PCR_ERR_ARG; }
 	ctx->prof = (on != 0);
+	ctx->prof_stride = (on > 1) ? (uint32_t)on : 1u; ctx->prof_pass = 0;
 	return PCR_OK;
 }
 
