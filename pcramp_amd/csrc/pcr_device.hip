@@ -1536,7 +1536,6 @@ int drain(pcr_ctx *ctx)
 		uint32_t c[4];
 		if((rc = mail_wait(ctx, pend[i].seq, c)) != PCR_OK) return rc;
 		SeqSet &S = ctx->sets[pend[i].which];
-		if(c[3] == N_TOUCHED_UNKNOWN_DEV && (c[1] & 1u)){ g_err = "Sequence::has_split: range is out of bounds"; return PCR_ERR_RANGE; }   // sequence.cpp:306-308 (fused tail)
 		if(!(c[0] & 1u)){
 			if(c[3] == N_TOUCHED_UNKNOWN_DEV){ S.n_touched = N_TOUCHED_UNKNOWN; S.n_entries = 1; }
 			else{ S.n_touched = c[3]; S.n_entries = c[3] ? 1 : 0; }
