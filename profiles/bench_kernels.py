@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Secondary figures SURVEY.md section 8(d) asks for, through the C-ABI (host buffers in, host buffers
+out, so PCIe and launch overhead are included -- end-to-end per call, not kernel-only):
+  * Smith-Waterman (pcr_sw_align_words, SeqOverlap lanes): GCUPS, cells = |q| x |t| per lane
+  * thermodynamics (pcr_thermo = PCR::is_valid incl. hairpin + homodimer): oligos/s
+  * local-search move evaluation (pcr_move_coverage): trial words/s at C2 scale
+Prints one JSON object.  python profiles/bench_kernels.py"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from pcramp_amd import api, synth, words as W  # noqa: E402
+
+
+def main():
+    rs = np.random.RandomState(1)
+    scr = api.Screener(0)
+    out = {}
+    # ---- SW lanes: 32-slot word against 32-slot word (the shape find_background_match uses per candidate)
+    n = 200_000
+    def rand_word(k):
+        return W.centered_word(2 ** rs.randint(0, 4, size=k).astype(np.uint8))
+    q = [rand_word(rs.randint(18, 26)) for _ in range(2000)]
+    t = [rand_word(32) for _ in range(2000)]
+    qs = [q[i % 2000] for i in range(n)]
+    ts = [t[(7 * i) % 2000] for i in range(n)]
+    scr.sw_align_words(qs[:1000], ts[:1000])
+    qa = np.array([[w[0], w[1]] for w in qs], dtype=np.uint64)
+    ta = np.array([[w[0], w[1]] for w in ts], dtype=np.uint64)
+    res = (api.SwResult * n)()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        scr._check(scr.L.pcr_sw_align_words(scr.h, qa.ctypes.data, ta.ctypes.data, n, res))
+    dt = (time.perf_counter() - t0) / 3
+    cells = sum(sum(1 for v in W.slots_from_word(a) if v) for a in q) / 2000.0 * 32
+    out["sw"] = {"lanes": n, "seconds_per_call": dt, "lanes_per_s": n / dt, "GCUPS": n * cells / dt / 1e9,
+                 "cells_per_lane": cells}
+    # ---- thermo: is_valid with hairpin + homodimer
+    m = 20_000
+    ol = [rand_word(rs.randint(18, 26)) for _ in range(m)]
+    scr.is_valid(ol[:256], True)
+    t0 = time.perf_counter()
+    scr.is_valid(ol, True)
+    dt = time.perf_counter() - t0
+    out["thermo"] = {"oligos": m, "seconds_per_call": dt, "oligos_per_s": m / dt}
+    # ---- move evaluation at C2 scale: all +degeneracy trials of one oligo (~60) in one call
+    wl = synth.workload("C2", 0, 1.0)
+    scr.load_sequences(wl["packed"], wl["byte_offsets"], wl["lengths"])
+    thr = float(np.float32(1.0) * np.float32(0.9))
+    scr.select_words(wl["pairs"], thr, 18, True, True)
+    p = wl["pairs"][0]
+    trials = api.host_move_trials(p[0], 0, 16, 18, 25)
+    scr.move_coverage(p, 0, trials)
+    t0 = time.perf_counter()
+    reps = 20
+    for _ in range(reps):
+        scr.move_coverage(p, 0, trials)
+    dt = (time.perf_counter() - t0) / reps
+    out["move_coverage"] = {"trials_per_call": len(trials), "targets": wl["T"], "seconds_per_call": dt,
+                            "trial_x_target_evals_per_s": len(trials) * wl["T"] / dt}
+    scr.close()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
