@@ -248,5 +248,14 @@ def test_screen_device_replays_after_bucket_overflow(oracle):
         got2 = _to_bool(o2[:, :1], len(seqs))
         assert np.array_equal(got2[0][0], want[0][2])
         assert np.array_equal(got2[1][0], want[1][2])
+        # the buckets have grown past the 64 slots the one-launch tail handles: the next asynchronous pass takes
+        # the k_touched / k_finalize / k_match / k_pair route with the touched count read on the device
+        o3 = torch.full((2, len(pairs), words), -1, dtype=torch.int64, device="cuda:0")
+        a.screen_device(pairs, thr, o3[0].data_ptr(), o3[1].data_ptr(), 1.0, 1.0, 80, 200, False)
+        a.synchronize()
+        torch.cuda.synchronize()
+        got3 = _to_bool(o3, len(seqs))
+        assert np.array_equal(got3[0], want[0]) and np.array_equal(got3[1], want[1])
+        assert len(a.entries()) > 64
     finally:
         a.close()
