@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--gather-every", type=int, default=8,
                     help="N>1: passes per all-gather (their bitsets travel in one collective)")
+    ap.add_argument("--optimize-shifts", action="store_true",
+                    help="diagnostic: --optimize.5/--optimize.3 of the reference (every 5'/3' slot shift of every oligo is a candidate)")
     ap.add_argument("--separate-calls", action="store_true",
                     help="pcr_select_words + pcr_amplify_device per step (host wait between them) instead of pcr_screen_device")
     ap.add_argument("--target-threshold", type=float, default=1.0,
@@ -161,14 +163,14 @@ def main():
         if timing:
             t_a = time.perf_counter()
         if args.separate_calls:
-            scr.select_words(pa, select_thr, 18, count=False)
+            scr.select_words(pa, select_thr, 18, args.optimize_shifts, args.optimize_shifts, count=False)
         if timing:
             t_b = time.perf_counter()
         if args.separate_calls:
             scr.amplify_device(pa, p_fr, p_rf, thr_t, thr_t, 80, 200, False)
         else:
             # one optimiser iteration's DB build + find_target_match, enqueued without a host wait
-            scr.screen_device(pa, select_thr, p_fr, p_rf, thr_t, thr_t, 80, 200, False, 18)
+            scr.screen_device(pa, select_thr, p_fr, p_rf, thr_t, thr_t, 80, 200, False, 18, args.optimize_shifts, args.optimize_shifts)
         if timing:
             t_c = time.perf_counter()
             host_t[0] += t_b - t_a
