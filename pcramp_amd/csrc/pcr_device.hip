@@ -603,7 +603,7 @@ struct pcr_ctx {
 	uint32_t n_cu = 256;        // compute units of the device (hipDeviceProp)
 	uint32_t bucket_cap = 64;   // hit slots per sequence (grows on overflow)
 	DevBuf<uint64_t> fin_scratch;   // k_finalize_big's keys
-	std::vector<uint16_t> seed_count; std::vector<uint8_t> seed_fill;   // host scratch of the seed-table builder
+	std::vector<uint16_t> seed_count; std::vector<uint8_t> seed_fill, seed_own;   // host scratch of the seed-table builder
 	uint32_t epoch = 0;         // pass counter tagging best[] (see HitSink)
 	uint64_t best_seen = 0;      // generation of best[] that has been cleared (the allocator may hand the same address back: never compare pointers)
 	// pinned staging for the small per-call host->device payload (candidates, tables, oligos): one async copy
@@ -1265,11 +1265,29 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 	const uint32_t n_or = 2*ncand;
 	std::vector<uint32_t> or_seed, or_plain;          // orientation ids
 	std::vector<pcrhost::Seed> seeds;
+	std::vector<std::vector<std::pair<uint16_t, int8_t> > > inheritors;   // per orientation: (shifted orientation, shift) sharing its seeds
+	size_t n_inherited = 0;
 	if(ctx->scan_version == 3 && n_or <= 65535){
+		// a 5'/3' shift candidate inherits the seeds of the unshifted oligo, moved by its shift, as long as no
+		// padded 8-window would have to be clamped at the end of the word (it costs 1/10 of deriving them anew)
+		struct OrientInfo { uint32_t begin, end; int max_exact_pos; bool seeded; };
+		std::vector<OrientInfo> info(n_or);
+		inheritors.assign(n_or, std::vector<std::pair<uint16_t, int8_t> >());
+		seeds.reserve((size_t)n_or*32);
 		for(uint32_t o = 0;o < n_or;++o){
 			const pcrhost::Candidate &c = cand[o >> 1];
-			if(pcrhost::orientation_seeds((o & 1) ? c.rc : c.fwd, c.floor_, o, seeds)) or_seed.push_back(o);
-			else or_plain.push_back(o);
+			OrientInfo &me = info[o];
+			me.begin = (uint32_t)seeds.size(); me.max_exact_pos = -1;
+			const uint32_t bo = 2*c.base + (o & 1u);
+			const int32_t sh = (o & 1u) ? -c.shift : c.shift;
+			if(c.base != (o >> 1) && info[bo].seeded && info[bo].max_exact_pos <= 24 && info[bo].max_exact_pos + sh <= 24){
+				inheritors[bo].push_back(std::make_pair((uint16_t)o, (int8_t)sh));   // its seeds = those of bo with off + sh: expanded when the table is built
+				n_inherited += info[bo].end - info[bo].begin;
+				me.seeded = true; me.max_exact_pos = (info[bo].max_exact_pos < 0) ? -1 : info[bo].max_exact_pos + sh;
+			}
+			else me.seeded = pcrhost::orientation_seeds((o & 1) ? c.rc : c.fwd, c.floor_, o, seeds, &me.max_exact_pos);
+			me.end = (uint32_t)seeds.size();
+			if(me.seeded) or_seed.push_back(o); else or_plain.push_back(o);
 		}
 	}
 	else{ for(uint32_t o = 0;o < n_or;++o) or_plain.push_back(o); }
@@ -1278,17 +1296,20 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 	// code shared by more than 255 seeds, sends everything to the bit-sliced path.
 	std::vector<uint32_t> image, heads, multi;
 	SeedTables ST; memset(&ST, 0, sizeof(ST));
-	const size_t n_seeds = seeds.size();
+	const size_t n_seeds = seeds.size() + n_inherited;
 	if(!or_seed.empty()){
 		image.assign(SEED_IMAGE_WORDS, 0u);
 		ctx->seed_count.assign(65536, 0);
 		std::vector<uint16_t> &count = ctx->seed_count;
 		bool overflow = false;
 		uint32_t distinct = 0;
+		std::vector<uint8_t> &own = ctx->seed_own; own.assign(65536, 0);      // seeds listed under the code (its inheritors come on top)
 		for(const pcrhost::Seed &sd : seeds){
 			uint16_t &c = count[sd.code];
 			if(c == 0){ image[sd.code >> 5] |= 1u << (sd.code & 31); ++distinct; }
-			if(++c > 255){ overflow = true; break; }
+			c = (uint16_t)(c + 1 + (inheritors.empty() ? 0 : inheritors[sd.orient].size()));
+			if(c > 255){ overflow = true; break; }
+			++own[sd.code];
 		}
 		if(distinct > SEED_MAX_DISTINCT) overflow = true;
 		if(overflow){
@@ -1305,21 +1326,56 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 			for(const pcrhost::Seed &sd : seeds){
 				const uint32_t h = rank16[sd.code >> 5] + (uint32_t)__builtin_popcount(image[sd.code >> 5] & ((1u << (sd.code & 31)) - 1u));
 				if(count[sd.code] == 1){ heads[h] = SEED_SINGLE | ((uint32_t)sd.orient << 8) | sd.off; continue; }
-				if(heads[h] == 0){ heads[h] = 0x40000000u | n_multi; n_multi += count[sd.code]; }   // bit 30: range reserved, low bits = start
+				if(heads[h] == 0){ heads[h] = 0x40000000u | n_multi; n_multi += own[sd.code]; }   // bit 30: range reserved, low bits = start
 			}
-			multi.assign(n_multi, 0u);
+			std::vector<uint32_t> raw(n_multi, 0u);                  // per code, in generation order: orient | off << 24
 			std::vector<uint8_t> &fill = ctx->seed_fill; fill.assign(distinct, 0);
 			for(const pcrhost::Seed &sd : seeds){
 				if(count[sd.code] == 1) continue;
 				const uint32_t h = rank16[sd.code >> 5] + (uint32_t)__builtin_popcount(image[sd.code >> 5] & ((1u << (sd.code & 31)) - 1u));
 				const uint32_t start = heads[h] & 0x3FFFFFFFu;
-				multi[start + fill[h]++] = (uint32_t)sd.orient | ((uint32_t)sd.off << 24);
+				raw[start + fill[h]++] = (uint32_t)sd.orient | ((uint32_t)sd.off << 24);
 			}
+			// Group the seeds of a code: slot shifts of one oligo orientation (consecutive candidates, so consecutive
+			// here) whose base-aligned offset boff = off - shift is the same lie over the same target bases; their
+			// match count is taken once, with the unshifted orientation at window x - boff (layout: pcr_scan_seed.inc).
+			multi.clear(); multi.reserve(n_multi + n_multi/2 + 16);
 			for(uint32_t h = 0;h < distinct;++h){
 				if(heads[h] & SEED_SINGLE) continue;
-				const uint32_t start = heads[h] & 0x3FFFFFFFu;
-				heads[h] = (start << 8) | fill[h];
+				const uint32_t start = heads[h] & 0x3FFFFFFFu, n = fill[h];
+				const uint32_t out0 = (uint32_t)multi.size();
+				uint32_t header_at = 0, members = 0, cur_base = 0xFFFFFFFFu; int32_t cur_boff = -1;
+				for(uint32_t e = 0;e < n;++e){
+					const uint32_t sd = raw[start + e], orient = sd & 0xFFFFu, off = sd >> 24;
+					const pcrhost::Candidate &c = cand[orient >> 1];
+					const int32_t sh = (orient & 1u) ? -c.shift : c.shift;
+					int32_t boff = (int32_t)off - sh;
+					uint32_t base_orient = 2*c.base + (orient & 1u);
+					if(boff < 0 || boff > 24){ boff = (int32_t)off; base_orient = orient; }   // the unshifted window would leave the word: stands alone
+					if(members && base_orient == cur_base && boff == cur_boff && members < 256){
+						multi.push_back(sd); ++members;
+						multi[header_at] = SEED_GROUP | cur_base | ((uint32_t)cur_boff << 16) | ((members - 1) << 21);
+					}
+					else{
+						header_at = (uint32_t)multi.size(); members = 1; cur_base = base_orient; cur_boff = boff;
+						multi.push_back(SEED_GROUP | cur_base | ((uint32_t)cur_boff << 16));
+						multi.push_back(sd);
+					}
+					// the shift candidates that inherit this seed: same target bases, off moved by their shift
+					if(!inheritors.empty()){
+						for(const std::pair<uint16_t, int8_t> &in : inheritors[orient]){
+							if(members == 256){        // header field full: open another group with the same leader
+								header_at = (uint32_t)multi.size(); members = 0;
+								multi.push_back(SEED_GROUP | cur_base | ((uint32_t)cur_boff << 16));
+							}
+							multi.push_back((uint32_t)in.first | ((uint32_t)((int32_t)off + in.second) << 24)); ++members;
+							multi[header_at] = SEED_GROUP | cur_base | ((uint32_t)cur_boff << 16) | ((members - 1) << 21);
+						}
+					}
+				}
+				heads[h] = (out0 << 9) | ((uint32_t)multi.size() - out0);
 			}
+			n_multi = (uint32_t)multi.size();
 			if(n_multi >= (1u << 22)){ g_err = "pcr_select_words: seed table too large"; return PCR_ERR_CAPACITY; }
 		}
 	}

@@ -381,27 +381,31 @@ struct Candidate {
 	Planes fwd;      // masks as stored (match against plus-strand windows and irregular words)
 	Planes rc;       // reverse-complemented masks (match against plus-strand windows = minus-strand words)
 	uint32_t floor_;
+	uint32_t base;   // index of the unshifted candidate this one is a 5'/3' slot shift of (itself if unshifted)
+	int32_t shift;   // slots `fwd` is shifted by relative to that candidate (towards slot 31 = positive); rc is shifted by -shift
 };
 
 inline void build_candidates(const uint64_t *pairs /* n x {F[2],R[2]} */, uint32_t n_pairs, bool opt5, bool opt3,
 	float threshold, std::vector<Candidate> &out)
 {
-	auto emit = [&out, threshold](const Planes &w){
+	auto emit = [&out, threshold](const Planes &w, uint32_t base, int32_t shift){
 		Candidate c;
 		c.fwd = w;
 		c.rc = planes_revcomp(w);
 		c.floor_ = (unsigned)((float)(unsigned)planes_size(w)*threshold);
+		c.base = base; c.shift = shift;
 		out.push_back(c);
 	};
 	out.reserve(out.size() + 2*(size_t)n_pairs*((opt5 || opt3) ? 8 : 1));
 	for(uint32_t i = 0;i < n_pairs;++i){
 		for(int o = 0;o < 2;++o){
 			const Planes base = planes_of_word(pairs + 4*i + 2*o);
-			emit(base);
+			const uint32_t bi = (uint32_t)out.size();
+			emit(base, bi, 0);
 			if(opt5 || opt3){
 				const int cs = planes_start(base), ce = planes_stop(base);
-				if(opt5 && cs > 0){ Planes t = base; for(int j = 0;j < cs;++j){ t = planes_shift_left(t); emit(t); } }
-				if(opt3 && ce < 31){ Planes t = base; for(int j = ce;j < 31;++j){ t = planes_shift_right(t); emit(t); } }
+				if(opt5 && cs > 0){ Planes t = base; for(int j = 0;j < cs;++j){ t = planes_shift_left(t); emit(t, bi, -(j + 1)); } }
+				if(opt3 && ce < 31){ Planes t = base; for(int j = ce;j < 31;++j){ t = planes_shift_right(t); emit(t, bi, j - ce + 1); } }
 			}
 		}
 	}
@@ -511,8 +515,11 @@ inline unsigned seed_count(const unsigned sets[SEED_Q])
 }
 
 // Appends the seeds of one orientation; returns false (nothing appended) if it cannot be seeded.
-inline bool orientation_seeds(const Planes &m, uint32_t floor_, uint32_t orient, std::vector<Seed> &out)
+// max_exact_pos (optional): largest first slot of a budget-0 block (-1 if none); while it stays <= 24 under a
+// slot shift of the oligo the seeds of the shifted oligo are these seeds with `off` moved by the shift.
+inline bool orientation_seeds(const Planes &m, uint32_t floor_, uint32_t orient, std::vector<Seed> &out, int *max_exact_pos = nullptr)
 {
+	if(max_exact_pos) *max_exact_pos = -1;
 	const uint32_t occ = m.a | m.c | m.g | m.t;
 	const int size = __builtin_popcount(occ);
 	if(size == 0 || floor_ == 0 || floor_ > (uint32_t)size) return floor_ > (uint32_t)size;   // dead orientation: trivially "seeded" with no seeds
@@ -582,6 +589,7 @@ inline bool orientation_seeds(const Planes &m, uint32_t floor_, uint32_t orient,
 		unsigned sets[SEED_Q];
 		for(int j = 0;j < SEED_Q;++j){ const int sl = ws + j; sets[j] = (sl >= pos && sl < pos + q) ? slot_set[sl] : 15u; }
 		seed_emit(sets, orient, (uint32_t)ws, out);
+		if(max_exact_pos) *max_exact_pos = std::max(*max_exact_pos, pos);
 		pos += len;
 	}
 	for(int b = 0;b < n1;++b){
