@@ -299,7 +299,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(
 // outer loop, so their planes and floors are wave-uniform (scalar loads, SGPR operands): 4 and/or +
 // popcount + compare per (word, candidate).  grid.x = ceil(n_live / (IRR_THREADS*IRR_PER_LANE)).
 constexpr int IRR_THREADS = 256, IRR_PER_LANE = 2;
-struct IrrArgs { const IrrDev *irr; const uint32_t *perm; uint32_t n_live; };
+struct IrrArgs { const IrrDev *irr; const uint32_t *perm; uint32_t n_live; uint32_t off_mask; /* slot offsets used by forward seeds */ };
 
 // the work of irregular-scan workgroup `block` (IRR_THREADS lanes)
 __device__ __forceinline__ void scan_irr_block(uint32_t block, const IrrDev *__restrict__ irr, const uint32_t *__restrict__ perm, uint32_t n_live,
@@ -1267,6 +1267,7 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 	std::vector<pcrhost::Seed> seeds;
 	std::vector<std::vector<std::pair<uint16_t, int8_t> > > inheritors;   // per orientation: (shifted orientation, shift) sharing its seeds
 	size_t n_inherited = 0;
+	uint32_t irr_off_mask = 0;
 	if(ctx->scan_version == 3 && n_or <= 65535){
 		// a 5'/3' shift candidate inherits the seeds of the unshifted oligo, moved by its shift, as long as no
 		// padded 8-window would have to be clamped at the end of the word (it costs 1/10 of deriving them anew)
@@ -1304,6 +1305,11 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 		bool overflow = false;
 		uint32_t distinct = 0;
 		std::vector<uint8_t> &own = ctx->seed_own; own.assign(65536, 0);      // seeds listed under the code (its inheritors come on top)
+		for(const pcrhost::Seed &sd : seeds){                                 // slot offsets at which forward seeds sit (irregular-word scan)
+			if(sd.orient & 1u) continue;
+			irr_off_mask |= 1u << sd.off;
+			if(!inheritors.empty()){ for(const std::pair<uint16_t, int8_t> &in : inheritors[sd.orient]) irr_off_mask |= 1u << (sd.off + in.second); }
+		}
 		for(const pcrhost::Seed &sd : seeds){
 			uint16_t &c = count[sd.code];
 			if(c == 0){ image[sd.code >> 5] |= 1u << (sd.code & 31); ++distinct; }
@@ -1492,7 +1498,7 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 					const dim3 sgrid(std::min<uint32_t>((S.n_tiles + tiles_per_wg - 1)/tiles_per_wg, resident)), sblock(SEED_THREADS);
 					// the irregular words ride along as extra workgroups behind the persistent ones: they fill the
 					// issue slots the latency-bound seed scan leaves idle instead of running alone afterwards
-					IrrArgs IA; IA.irr = S.irr.p; IA.perm = S.irr_perm.p; IA.n_live = n_live;
+					IrrArgs IA; IA.irr = S.irr.p; IA.perm = S.irr_perm.p; IA.n_live = n_live; IA.off_mask = or_plain.empty() ? irr_off_mask : 0u;   // the seeded irregular scan needs every candidate seeded
 					const uint32_t irr_wgs = (n_live + IRR_THREADS*IRR_PER_LANE - 1)/(IRR_THREADS*IRR_PER_LANE);
 					const dim3 fgrid(sgrid.x + irr_wgs);
 					irr_fused = true;
