@@ -74,7 +74,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--random-primers", action="store_true", help="diagnostic: primers unrelated to the targets (no hits)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--gather-every", type=int, default=8,
+    ap.add_argument("--gather-every", type=int, default=16,
                     help="N>1: passes per all-gather (their bitsets travel in one collective)")
     ap.add_argument("--optimize-shifts", action="store_true",
                     help="diagnostic: --optimize.5/--optimize.3 of the reference (every 5'/3' slot shift of every oligo is a candidate)")
