@@ -1300,11 +1300,13 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 	const size_t n_seeds = seeds.size() + n_inherited;
 	if(!or_seed.empty()){
 		image.assign(SEED_IMAGE_WORDS, 0u);
-		ctx->seed_count.assign(65536, 0);
+		// count[] / own[] (one entry per 8-gram code) are kept all-zero between passes: only the entries a pass touched
+		// are cleared again (two 64K-entry memsets per pass were ~8 us of the host plan)
+		if(ctx->seed_count.size() != 65536){ ctx->seed_count.assign(65536, 0); ctx->seed_own.assign(65536, 0); }
 		std::vector<uint16_t> &count = ctx->seed_count;
 		bool overflow = false;
 		uint32_t distinct = 0;
-		std::vector<uint8_t> &own = ctx->seed_own; own.assign(65536, 0);      // seeds listed under the code (its inheritors come on top)
+		std::vector<uint8_t> &own = ctx->seed_own;                          // seeds listed under the code (its inheritors come on top)
 		for(const pcrhost::Seed &sd : seeds){                                 // slot offsets at which forward seeds sit (irregular-word scan)
 			if(sd.orient & 1u) continue;
 			irr_off_mask |= 1u << sd.off;
@@ -1382,9 +1384,10 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 				heads[h] = (out0 << 9) | ((uint32_t)multi.size() - out0);
 			}
 			n_multi = (uint32_t)multi.size();
-			if(n_multi >= (1u << 22)){ g_err = "pcr_select_words: seed table too large"; return PCR_ERR_CAPACITY; }
+			if(n_multi >= (1u << 22)){ ctx->seed_count.clear(); g_err = "pcr_select_words: seed table too large"; return PCR_ERR_CAPACITY; }
 		}
 	}
+	if(ctx->seed_count.size() == 65536){ for(const pcrhost::Seed &sd : seeds){ ctx->seed_count[sd.code] = 0; ctx->seed_own[sd.code] = 0; } }
 	if(getenv("PCRAMP_DEBUG")) fprintf(stderr, "[pcramp] scan plan: %u candidates, %zu seeded orientations (%zu seeds), %zu plain, %u/%u IUPAC tiles\n",
 		ncand, or_seed.size(), n_seeds, or_plain.size(), S.n_degen_tiles, S.n_tiles);
 	Scan2Tables tab_plain, tab_seedset;               // bit-sliced tables: unseedable orientations (all tiles) / seedable ones (IUPAC tiles)
