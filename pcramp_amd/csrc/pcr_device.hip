@@ -1527,14 +1527,17 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 				S.d_active.p, ctx->d_cand_fwd, ctx->d_cand_floor, ncand, sink);
 			HIP_TRY(hipGetLastError());
 		}
-		if(async && fa && fa->staged && cap == POST_CAP && 2*fa->n_pairs <= 32*POST_MASK_WORDS){
+		if(async && fa && fa->staged && (cap == POST_CAP || cap == 128 || cap == 256) && 2*fa->n_pairs <= 32*POST_MASK_WORDS){
 			// the whole tail -- DB finalisation and the amplicon screen -- in one launch
 			++ctx->mail_seq;
 			const uint64_t bw = (S.n + 63)/64;
-			hipLaunchKernelGGL(k_post, dim3((S.n + POST_WAVES - 1)/POST_WAVES), dim3(64*POST_WAVES), 0, ctx->stream, ctx->hits.p, d_seq_count,
-				ctx->best.p, ncand, S.planes.p, S.d_blk_off.p, S.irr.p, S.irr_off.p, S.db.p, S.d_seg_hi, d_counters, ctx->epoch, S.n,
-				fa->d_oligos, fa->n_pairs, (2*fa->n_pairs + 31)/32, S.d_len.p, S.d_active.p, fa->a->amp_min, fa->a->amp_max,
-				fa->a->ident_threshold, fa->a->use_taq_mama, fa->d_fr, fa->d_rf, bw, ctx->mail_dev + (ctx->mail_seq % pcr_ctx::MAIL_RING), ctx->mail_seq);
+#define POST_ARGS ctx->hits.p, d_seq_count, ctx->best.p, ncand, S.planes.p, S.d_blk_off.p, S.irr.p, S.irr_off.p, S.db.p, S.d_seg_hi, d_counters, ctx->epoch, S.n, \
+	fa->d_oligos, fa->n_pairs, (2*fa->n_pairs + 31)/32, S.d_len.p, S.d_active.p, fa->a->amp_min, fa->a->amp_max, \
+	fa->a->ident_threshold, fa->a->use_taq_mama, fa->d_fr, fa->d_rf, bw, ctx->mail_dev + (ctx->mail_seq % pcr_ctx::MAIL_RING), ctx->mail_seq
+			if(cap == POST_CAP) hipLaunchKernelGGL(k_post, dim3((S.n + POST_WAVES - 1)/POST_WAVES), dim3(64*POST_WAVES), 0, ctx->stream, POST_ARGS);
+			else if(cap == 128) hipLaunchKernelGGL((k_post_big<128, 4>), dim3((S.n + 3)/4), dim3(256), 0, ctx->stream, POST_ARGS);
+			else hipLaunchKernelGGL((k_post_big<256, 4>), dim3((S.n + 3)/4), dim3(256), 0, ctx->stream, POST_ARGS);
+#undef POST_ARGS
 			HIP_TRY(hipGetLastError());
 			fa->posted = true;
 			S.db_cap = cap; S.n_slots = n_slots;

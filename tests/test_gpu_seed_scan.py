@@ -259,3 +259,42 @@ def test_screen_device_replays_after_bucket_overflow(oracle):
         assert len(a.entries()) > 64
     finally:
         a.close()
+
+
+def test_screen_device_with_shift_candidates(oracle):
+    """--optimize.5/--optimize.3 (every slot shift of every oligo is a candidate): many words per site, so the
+    per-sequence buckets outgrow 64 slots and the one-launch tail runs in its 128- / 256-slot form.  The fused
+    asynchronous passes equal the synchronous calls, pass after pass."""
+    import torch
+    rng = random.Random(2024)
+    root = rand_seq(rng, 4000)
+    seqs = [root] + [mutate(rng, root, 0.02) for _ in range(30)] + [rand_seq(rng, 1500) for _ in range(4)]
+    pairs = []
+    for i in range(12):
+        a0 = rng.randrange(0, 3600)
+        f = root[a0:a0 + rng.randint(18, 25)]
+        r = revcomp(root[a0 + 110:a0 + 110 + rng.randint(18, 25)])
+        pairs.append((oracle.centered_word(f), oracle.centered_word(r)))
+    thr = float(np.float32(1.0) * np.float32(0.9))
+    d = _screener(None)
+    try:
+        d.load_texts(seqs, [1.0] * len(seqs))
+        n = d.select_words(pairs, thr, 18, True, True)
+        per_seq = {}
+        for e in d.entries():
+            per_seq[e[3]] = per_seq.get(e[3], 0) + 1
+        assert max(per_seq.values()) > 64                      # buckets must have grown
+        _, fr, rf, _ = d.amplify(pairs, 1.0, 1.0, 80, 200, False)
+        assert fr.any() or rf.any()
+        assert d.entries() == _oracle_entries(oracle, seqs, pairs, 1.0, 0.9, 1, 1)
+        words = int(d.bitset_words())
+        for rep in range(3):                                   # asynchronous passes with the grown buckets
+            o = torch.full((2, len(pairs), words), -1, dtype=torch.int64, device="cuda:0")
+            d.screen_device(pairs, thr, o[0].data_ptr(), o[1].data_ptr(), 1.0, 1.0, 80, 200, False, 18, True, True)
+            d.synchronize()
+            torch.cuda.synchronize()
+            got = _to_bool(o, len(seqs))
+            assert np.array_equal(got[0], fr) and np.array_equal(got[1], rf)
+            assert len(d.entries()) == n
+    finally:
+        d.close()
