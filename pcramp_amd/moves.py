@@ -95,13 +95,78 @@ def score_eq(a, b):
 DEFAULT_MOVES = (INCREASE_DEGENERACY, DECREASE_DEGENERACY, TRIM5, GROW5, TRIM3, GROW3)      # main.cpp:82-95
 
 
+def _evaluate_iteration(scr, approx, move_list, degen=1, primer_min=18, primer_max=25, salt=0.05, primer_strand=9.0e-7,
+                        tm_min=50.0, tm_max=70.0, max_hairpin=40.0, target_threshold=1.0, search_multiplier=0.9, amp_min=80,
+                        amp_max=200, use_taq_mama=False, bg_threshold=0.8, bg_multiplier=0.9, bg_amp_min=0, bg_amp_max=2000,
+                        have_background=True):
+    """Everything one optimize() iteration needs from the device, in five calls instead of three per move: the
+    trial words of every move of both oligos, their is_valid flags, their target and background coverage.
+    Coverage does not depend on the running score threshold, so the moves can be decided on the host afterwards
+    in the reference's order.  -> {(side, move): [(word, valid, tc, bc), ...]}"""
+    per = {}
+    flat = {0: [], 1: []}
+    for side in (0, 1):
+        for mv in move_list:
+            tr = api.host_move_trials(approx[side], mv, degen, primer_min, primer_max)
+            per[(side, mv)] = (len(flat[side]), len(tr))
+            flat[side] += tr
+    allw = flat[0] + flat[1]
+    ok = [r["valid"] for r in scr.is_valid(allw, check_homo_dimer=False, salt=salt, primer_strand=primer_strand, tm_min=tm_min,
+                                           tm_max=tm_max, max_hairpin=max_hairpin, max_dimer=0.0)] if allw else []
+    out = {}
+    base = 0
+    for side in (0, 1):
+        words = flat[side]
+        valid = ok[base:base + len(words)]
+        base += len(words)
+        live = [w for w, v in zip(words, valid) if v]
+        tcov = bcov = []
+        if live:
+            tcov, _, _ = scr.move_coverage(approx, side, live, target_threshold, search_multiplier, amp_min, amp_max, use_taq_mama,
+                                           which=api.TARGET)
+            if have_background:
+                bcov, _, _ = scr.move_coverage(approx, side, live, bg_threshold, bg_multiplier, bg_amp_min, bg_amp_max,
+                                               use_taq_mama, which=api.BACKGROUND)
+            else:
+                bcov = np.zeros(len(live), np.float32)
+        it = iter(zip(tcov, bcov))
+        rows = []
+        for w, v in zip(words, valid):
+            if v:
+                tc, bc = next(it)
+                rows.append((w, True, np.float32(tc), np.float32(bc)))
+            else:
+                rows.append((w, False, None, None))
+        for mv in move_list:
+            lo, n = per[(side, mv)]
+            out[(side, mv)] = rows[lo:lo + n]
+    return out
+
+
+def _decide_move(rows, score_threshold):
+    """One move function's loop over its trials (optimize_pcr.cpp): is_valid gate, coverage-bound shortcut
+    (:95-109), Score comparison.  rows: [(word, valid, tc, bc)]."""
+    best_w, best = (0, 0), EMPTY_SCORE
+    for w, valid, tc, bc in rows:
+        if not valid:
+            continue
+        bound = np.float32(np.float32(tc) + np.float32(score_threshold[1])) - np.float32(score_threshold[0])
+        if bound <= 0.0:
+            continue
+        trial = (np.float32(tc), np.float32(bc), np.float32(0.0))
+        if score_gt(trial, best):
+            best, best_w = trial, w
+    return best_w, best
+
+
 def optimize(scr, pair, move_list=DEFAULT_MOVES, **opts):
     """optimize() (optimize.cpp:14-207), non-multiplex: greedy local search over both oligos.
 
     Per iteration: score of the current assay (collect + update + compute coverage, :61-79), every move of
     every oligo against the running best (`local_score` doubles as the moves' score threshold, :126-130; ties
     go to the lower degeneracy, :133-135), the winner re-centred and installed (:152-154); stops when nothing
-    improves, when the score drops, or when an assay repeats (:196-202).  -> (best pair, Score)."""
+    improves, when the score drops, or when an assay repeats (:196-202).  The device is asked once per
+    iteration for all trial words of all moves (`_evaluate_iteration`).  -> (best pair, Score)."""
     cov_kw = {k: opts[k] for k in ("target_threshold", "search_multiplier", "amp_min", "amp_max", "use_taq_mama",
                                    "bg_threshold", "bg_multiplier", "bg_amp_min", "bg_amp_max", "have_background") if k in opts}
     best = (tuple(int(x) for x in pair[0]), tuple(int(x) for x in pair[1]))
@@ -114,10 +179,11 @@ def optimize(scr, pair, move_list=DEFAULT_MOVES, **opts):
         if score_lt(approx_score, best_score):
             break
         best_score, best = approx_score, approx
+        evaluated = _evaluate_iteration(scr, approx, move_list, **opts)
         local_seq, local_oligo, local_score, improved = (0, 0), None, approx_score, False
         for side in (0, 1):
             for mv in move_list:
-                w, sc = optimization_move(scr, approx, mv, side, score_threshold=local_score, **opts)
+                w, sc = _decide_move(evaluated[(side, mv)], local_score)
                 if score_gt(sc, local_score) or (score_eq(sc, local_score) and W.word_degeneracy(w) < W.word_degeneracy(local_seq)):
                     local_score, local_seq, local_oligo, improved = sc, w, side, True
         if not improved:
