@@ -245,6 +245,38 @@ int pcr_dimer(pcr_ctx *ctx, const pcr_pair *pairs, uint32_t n, const pcr_thermo_
 int pcr_multiplex_compatible(pcr_ctx *ctx, const pcr_pair *a, const pcr_pair *b, uint32_t n,
 	const pcr_thermo_args *args, uint8_t *ok);
 
+/* ---- Random assay sampler (scope row f-2) */
+
+/* The `Options` fields PCR::random_assay reads besides the thermodynamic ones (pcramp.h:21-30). */
+typedef struct {
+	int32_t primer_min, primer_max;  /* opt.primer_range */
+	int32_t amp_min, amp_max;        /* opt.target_amplicon_range */
+	double  max_degen;               /* opt.degen */
+} pcr_sampler_args;
+
+typedef struct {
+	uint32_t sequence;               /* index of the sequence the assay was cut from */
+	int32_t  f_start;                /* 0-based start of the forward primer */
+	int32_t  amplicon_length;        /* the "Amplicon length" of the verbose line, pcr_assay.cpp:728 */
+	uint32_t sequence_iterations;    /* "tried N seq ..." */
+	uint32_t assay_iterations;       /* "... and M assays" (of the last sequence tried) */
+} pcr_sample_info;
+
+/* PCR::random_assay (pcr_assay.cpp:580-734) for n_trials fresh assays drawn one after the other from the
+ * running glibc rand_r state *seed -- the body of the sampling loop main.cpp:544-550 as one thread executes
+ * it (the caller obtains that thread's seed with pcr_host_rand_r(&global_seed), main.cpp:541-542).
+ * Sequences, their active flags and their EOS splits are those of set `which` as loaded.  Validity
+ * (is_valid with the homodimer test, max_dimer_tm) is evaluated on the device: the thermodynamic jobs of
+ * every attempt that could start inside a window of the random stream go out as one launch.
+ * pairs_out[i] = the centred assay of trial i; info_out is optional.  Where the reference throws
+ * ("No active sequences found", "sequence length is too small!", "Unable to generate a valid initial
+ * assay to test!", Sequence::subword out of bounds) an error code is returned with that text. */
+int pcr_random_assays(pcr_ctx *ctx, pcr_set which, uint32_t *seed, uint32_t n_trials, const pcr_sampler_args *sampler,
+	const pcr_thermo_args *thermo, pcr_pair *pairs_out, pcr_sample_info *info_out);
+
+/* glibc rand_r (the reference's random source, sample.cpp:12), restated; usable without a GPU. */
+uint32_t pcr_host_rand_r(uint32_t *seed);
+
 /* ---- Host-only helpers (pure CPU arithmetic of the host half of the index build; usable
  * without a GPU; exercised by the `not gpu` tests). */
 

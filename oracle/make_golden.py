@@ -251,12 +251,63 @@ def moves_golden(ref):
     return {"cases": cases}
 
 
+def sampler_inputs(ci):
+    """Targets of the sampler cases: families with an IUPAC stretch, an EOS split, an inactive record and, for
+    case 3, records barely longer than the amplicon."""
+    rng = random.Random(3100 + ci)
+    if ci == 3:
+        seqs = [rand_seq(rng, n) for n in (41, 44, 47, 60, 75)]
+        return seqs, [True] * len(seqs), []
+    seqs = family_targets(rng, 3, 5, 700, div=0.05) + [rand_seq(rng, 333)]
+    q = list(seqs[2])
+    for k in range(300, 420, 9):
+        q[k] = rng.choice("RYKMSWN")
+    seqs[2] = "".join(q)
+    active = [i != 4 for i in range(len(seqs))]
+    return seqs, active, [(1, 350), (7, 100)]
+
+
+SAMPLER_CASES = [dict(), dict(max_degen=4.0, tm_min=45.0, tm_max=75.0), dict(tm_min=58.0, tm_max=60.0, max_hairpin=25.0, max_dimer=20.0),
+                 dict(primer_min=18, primer_max=22, amp_min=38, amp_max=60, tm_min=40.0, tm_max=80.0)]
+
+
+def sampler_golden(ref):
+    """PCR::random_assay as the one-thread sampling loop of main.cpp:544-550 runs it: n trials per seed on one
+    running rand_r state; the assays and the state afterwards.  Plus raw rand_r values."""
+    from oracle_lib import random_assays, rand_r, DEFAULT_SAMPLER_OPTIONS
+    stream = []
+    for seed in (0, 1, 42, 0x7fffffff, 0xdeadbeef, 0xffffffff):
+        s, vals = seed, []
+        for _ in range(6):
+            v, s = rand_r(ref, s)
+            vals.append(v)
+        stream.append([seed, vals, s])
+    cases = []
+    for ci, case in enumerate(SAMPLER_CASES):
+        seqs, active, splits = sampler_inputs(ci)
+        sess = ref.session()
+        for q, a in zip(seqs, active):
+            sess.add_target(q, 1.0, a)
+        for i, pos in splits:
+            sess.split(i, pos)
+        runs = []
+        for seed in (1, 2, 3, 77, 4242, 0x9e3779b9):
+            pairs, after = random_assays(ref, sess, seed, 6, **case)
+            runs.append([seed, [hexw(f) + hexw(r) for f, r in pairs], after])
+        so = dict(DEFAULT_SAMPLER_OPTIONS); so.update(case)
+        cases.append({"sampler_options": so, "seqs": seqs, "active": active, "splits": splits, "runs": runs})
+    return {"rand_r": stream, "cases": cases}
+
+
 def main():
     build_reference()
     ref = Reference()
     os.makedirs(OUT, exist_ok=True)
+    only = set(sys.argv[1:])
     for name, fn in (("words", words_golden), ("pack", pack_golden), ("screen", screen_golden), ("sw", sw_golden),
-                     ("thermo", thermo_golden), ("moves", moves_golden)):
+                     ("thermo", thermo_golden), ("moves", moves_golden), ("sampler", sampler_golden)):
+        if only and name not in only:
+            continue
         with open(os.path.join(OUT, name + ".json"), "w") as f:
             json.dump(fn(ref), f, separators=(",", ":"))
         print("wrote", name, os.path.getsize(os.path.join(OUT, name + ".json")), "bytes")

@@ -1011,3 +1011,94 @@ int orc_session_multiplex_match(orc_session *s, const uint64_t pair[4], float bg
 }
 
 } // extern "C"
+
+// ------------------------------------------------------------------------------------ sampler (row f-2)
+extern "C" unsigned orc_rand_r(unsigned *seed)                                    // glibc 2.35 stdlib/rand_r.c
+{
+	unsigned next = *seed;
+	int result;
+	next *= 1103515245u; next += 12345u;
+	result = (int)((next/65536u) % 2048u);
+	next *= 1103515245u; next += 12345u;
+	result <<= 10; result ^= (int)((next/65536u) % 1024u);
+	next *= 1103515245u; next += 12345u;
+	result <<= 10; result ^= (int)((next/65536u) % 1024u);
+	*seed = next;
+	return (unsigned)result;
+}
+
+namespace {
+
+int random_location(int start, int stop, unsigned *seed)                           // sample.cpp:6-12
+{
+	if(stop == start) throw "random_location: empty interval (the reference divides by zero)";
+	return start + (int)orc_rand_r(seed) % (stop - start);
+}
+
+W subword(const Seq &s, int64_t loc, int len)                                     // sequence.cpp:269-302
+{
+	if(loc < 0 || (uint64_t)(loc + len) > s.len) throw "Sequence::subword: word is out of bounds";
+	W r;
+	for(int i = 0;i < len;++i) r.push_back(s.at((uint64_t)(loc + i)));             // an EOS nibble adds nothing
+	return r;
+}
+
+bool valid_oligo(const W &w, const orc_sampler_options *o)
+{
+	const int r = orc_is_valid(w.b, o->salt, o->primer_strand, o->tm_min, o->tm_max, o->max_hairpin, o->max_dimer, 1);
+	if(r < 0) throw "is_valid failed";
+	return r == 1;
+}
+
+void random_assay(const std::vector<Seq> &seqs, unsigned *seed, const orc_sampler_options *o, W &f, W &r)   // pcr_assay.cpp:580-734
+{
+	std::vector<size_t> idx;
+	for(size_t i = 0;i < seqs.size();++i){ if(seqs[i].active) idx.push_back(i); }  // :593-599
+	if(idx.empty()) throw "PCR::random_assay: No active sequences found";
+	const int span = o->primer_max - o->primer_min + 1;
+	for(unsigned seq_iter = 1;;++seq_iter){
+		if(seq_iter > 100) throw "PCR::random_assay: Unable to generate a valid initial assay to test!";   // :611-613
+		const Seq &t = seqs[idx[orc_rand_r(seed) % idx.size()]];                   // :618
+		const int len = (int)t.len;
+		if(len < o->amp_min) throw "PCR::random_assay: sequence length is too small!";
+		for(unsigned assay_iter = 1;assay_iter <= 100;++assay_iter){               // :626-634
+			const int f_len = o->primer_min + (int)orc_rand_r(seed) % span;         // :637-638
+			const int r_len = o->primer_min + (int)orc_rand_r(seed) % span;
+			if(f_len + r_len > len) continue;
+			const int f_start = random_location(0, (len + 1) - o->amp_min, seed);   // :644
+			f = subword(t, f_start, f_len);
+			if((int)f.size() != f_len) continue;                                    // :649
+			if(f.degeneracy() > o->max_degen) continue;                             // :655
+			if(!valid_oligo(f, o)) continue;                                        // :662
+			const int r_start = random_location(f_start + o->amp_min - r_len,       // :677-679
+				std::min((len + 1) - r_len, (f_start + o->amp_max + 1) - r_len), seed);
+			const int amp_len = r_start - f_start + r_len;
+			if(amp_len > o->amp_max || amp_len < o->amp_min) continue;              // :683-686
+			r = subword(t, r_start, r_len).complement();                            // :688
+			if((int)r.size() != r_len) continue;
+			if(r.degeneracy() > o->max_degen) continue;                             // :697
+			if(has_split(t, f_start, amp_len)) continue;                            // :703
+			if(!valid_oligo(r, o)) continue;                                        // :710
+			uint64_t pr[4] = {f.b[0], f.b[1], r.b[0], r.b[1]};
+			if(orc_max_dimer_tm(pr, o->salt, o->primer_strand) > o->max_dimer) continue;   // :715
+			f.center(); r.center();                                                 // :719
+			return;
+		}
+	}
+}
+
+} // namespace
+
+extern "C" int orc_random_assays(orc_session *s, unsigned *seed, unsigned n_trials, const orc_sampler_options *o, uint64_t *pairs_out)
+{
+	try{
+		W f, r;                                                                     // each trial is a fresh PCR (main.cpp:525)
+		for(unsigned t = 0;t < n_trials;++t){
+			f = W(); r = W();
+			random_assay(s->seq, seed, o, f, r);
+			pairs_out[4*t] = f.b[0]; pairs_out[4*t + 1] = f.b[1]; pairs_out[4*t + 2] = r.b[0]; pairs_out[4*t + 3] = r.b[1];
+		}
+		return 0;
+	}
+	catch(const char *e){ s->err = e; return -1; }
+}

@@ -148,6 +148,21 @@ float orc_max_dimer_tm(const uint64_t pair[4], float salt, float primer_strand);
 // PCR::multiplex_compatible (pcr_assay.cpp:815-852), a = this assay, b = argument
 int orc_multiplex_compatible(const uint64_t a[4], const uint64_t b[4], float salt, float primer_strand, float max_dimer);
 
+// ---- random assay sampler (scope row f-2)
+typedef struct {
+	int primer_min, primer_max;      // opt.primer_range
+	int amp_min, amp_max;            // opt.target_amplicon_range
+	double max_degen;                // opt.degen
+	float salt, primer_strand, tm_min, tm_max, max_hairpin, max_dimer;
+} orc_sampler_options;
+// glibc rand_r (the reference's only random source, sample.cpp:12, pcr_assay.cpp:614-636; glibc 2.35
+// stdlib/rand_r.c: three steps of the LCG x*1103515245+12345, 11+10+10 result bits).
+unsigned orc_rand_r(unsigned *seed);
+// PCR::random_assay (pcr_assay.cpp:580-734) n_trials times on one running seed, as the one-thread
+// sampling loop of main.cpp:544-550 does.  pairs_out: n x {F[2], R[2]}, centred.  Returns 0, or <0
+// where the reference throws (error text in orc_session_error).
+int orc_random_assays(orc_session *s, unsigned *seed, unsigned n_trials, const orc_sampler_options *o, uint64_t *pairs_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -694,6 +694,42 @@ int ref_multiplex_compatible(const uint64_t a[4], const uint64_t b[4], float sal
 	catch(...){ return -1; }
 }
 
+// PCR::random_assay (pcr_assay.cpp:580-734) for n_trials fresh assays on one running seed -- the body of
+// the one-thread sampling loop, main.cpp:544-550.  One NucCruc serves all calls, as there; it is pre-filled
+// once (see prefill), so later calls see whatever earlier queries left in the rings, as in the program.
+struct RefSamplerOptions {
+	int primer_min, primer_max, amp_min, amp_max;
+	double max_degen;
+	float salt, primer_strand, tm_min, tm_max, max_hairpin, max_dimer;
+};
+
+unsigned ref_rand_r(unsigned *seed) { return (unsigned)rand_r(seed); }
+
+int ref_random_assays(RefSession *s, unsigned *seed, unsigned n_trials, const RefSamplerOptions *o, uint64_t *pairs_out)
+{
+	try{
+		Options opt = s->opt;
+		opt.primer_range = make_pair(o->primer_min, o->primer_max);
+		opt.target_amplicon_range = make_pair(o->amp_min, o->amp_max);
+		opt.degen = o->max_degen;
+		opt.salt = o->salt;
+		thermo_options(opt, o->primer_strand, o->tm_min, o->tm_max, o->max_hairpin, o->max_dimer);
+		NucCruc melt;
+		prefill(melt);
+		melt.salt(opt.salt);
+		ostringstream sink;
+		for(unsigned t = 0;t < n_trials;++t){
+			PCR p;
+			p.random_assay(s->target_seq, melt, opt, *seed, sink);
+			words_of(p.oligo(FORWARD), pairs_out + 4*t);
+			words_of(p.oligo(REVERSE), pairs_out + 4*t + 2);
+		}
+		return 0;
+	}
+	catch(const char *e){ s->last_error = e; return -1; }
+	catch(...){ s->last_error = "unknown"; return -2; }
+}
+
 // The SantaLucia parameter set as the reference initialises it (published values:
 // SantaLucia & Hicks, Annu. Rev. Biophys. Biomol. Struct. 33:415-440, 2004), for
 // oracle/gen_thermo_tables.py.  scalars: init_H, init_S, asymmetric_loop_dS, bulge_AT_closing_S,

@@ -55,6 +55,16 @@ class ThermoArgs(C.Structure):
                 ("max_hairpin", C.c_float), ("max_dimer", C.c_float)]
 
 
+class SamplerArgs(C.Structure):
+    _fields_ = [("primer_min", C.c_int32), ("primer_max", C.c_int32), ("amp_min", C.c_int32), ("amp_max", C.c_int32),
+                ("max_degen", C.c_double)]
+
+
+class SampleInfo(C.Structure):
+    _fields_ = [("sequence", C.c_uint32), ("f_start", C.c_int32), ("amplicon_length", C.c_int32),
+                ("sequence_iterations", C.c_uint32), ("assay_iterations", C.c_uint32)]
+
+
 class ThermoResult(C.Structure):
     _fields_ = [("valid", C.c_uint32), ("n_expansions", C.c_uint32), ("tm", C.c_float), ("dH", C.c_float), ("dS", C.c_float),
                 ("hairpin_tm", C.c_float), ("homodimer_tm", C.c_float), ("pad", C.c_uint32)]
@@ -80,6 +90,7 @@ ABI_SYMBOLS = [
     "pcr_host_orientation_seeds", "pcr_host_move_trials",
     "pcr_sw_align_words", "pcr_background_match", "pcr_multiplex_match",
     "pcr_thermo", "pcr_dimer", "pcr_multiplex_compatible",
+    "pcr_random_assays", "pcr_host_rand_r",
 ]
 
 
@@ -132,6 +143,10 @@ def load_library():
     L.pcr_thermo.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.POINTER(ThermoArgs), C.c_void_p]
     L.pcr_dimer.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(ThermoArgs), C.c_void_p]
     L.pcr_multiplex_compatible.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(ThermoArgs), C.c_void_p]
+    L.pcr_random_assays.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(SamplerArgs),
+                                    C.POINTER(ThermoArgs), C.c_void_p, C.c_void_p]
+    L.pcr_host_rand_r.restype = C.c_uint32
+    L.pcr_host_rand_r.argtypes = [C.POINTER(C.c_uint32)]
     L.pcr_host_irregular_words.restype = C.c_int64
     L.pcr_host_irregular_words.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(_Params), C.c_uint32, C.c_void_p, C.c_uint64]
     L.pcr_host_window_valid.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(_Params), C.c_void_p]
@@ -174,6 +189,14 @@ def host_window_valid(packed, length, pack_max_degen=256, pack_min_gc=0.0, pack_
     if L.pcr_host_window_valid(buf.ctypes.data, length, C.byref(p), out.ctypes.data) != 0:
         raise PcrError(_err(L))
     return out[:length]
+
+
+def host_rand_r(seed):
+    """glibc rand_r (sample.cpp:12) -> (value, next seed)."""
+    L = load_library()
+    s = C.c_uint32(int(seed))
+    v = L.pcr_host_rand_r(C.byref(s))
+    return int(v), int(s.value)
 
 
 def host_move_trials(word, move, max_degen=1, primer_min=18, primer_max=25):
@@ -424,6 +447,21 @@ class Screener:
         self._check(self.L.pcr_thermo(self.h, a.ctypes.data, len(oligos), int(check_homo_dimer), C.byref(args), out))
         return [dict(valid=bool(r.valid), n=r.n_expansions, tm=np.float32(r.tm), dH=np.float32(r.dH), dS=np.float32(r.dS),
                      hairpin_tm=np.float32(r.hairpin_tm), homodimer_tm=np.float32(r.homodimer_tm)) for r in out[:len(oligos)]]
+
+    def random_assays(self, seed, n_trials, primer_min=18, primer_max=25, amp_min=80, amp_max=200, max_degen=1.0, salt=0.05,
+                      primer_strand=9e-7, tm_min=50.0, tm_max=70.0, max_hairpin=40.0, max_dimer=40.0, which=TARGET):
+        """PCR::random_assay x n_trials on one running rand_r seed (main.cpp:544-550 at one thread)
+        -> ([(F, R)], seed afterwards, [info dict])."""
+        sa = SamplerArgs(primer_min, primer_max, amp_min, amp_max, max_degen)
+        ta = self._targs(salt, primer_strand, tm_min, tm_max, max_hairpin, max_dimer)
+        out = np.zeros((max(n_trials, 1), 4), dtype=np.uint64)
+        info = (SampleInfo * max(n_trials, 1))()
+        s = C.c_uint32(int(seed))
+        self._check(self.L.pcr_random_assays(self.h, which, C.byref(s), n_trials, C.byref(sa), C.byref(ta), out.ctypes.data, info))
+        pairs = [((int(r[0]), int(r[1])), (int(r[2]), int(r[3]))) for r in out[:n_trials]]
+        infos = [dict(sequence=i.sequence, f_start=i.f_start, amplicon_length=i.amplicon_length,
+                      sequence_iterations=i.sequence_iterations, assay_iterations=i.assay_iterations) for i in info[:n_trials]]
+        return pairs, int(s.value), infos
 
     def max_dimer_tm(self, pairs, salt=0.05, primer_strand=9e-7):
         """PCR::max_dimer_tm for a batch of pairs -> float32 array."""

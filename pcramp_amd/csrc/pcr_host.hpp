@@ -451,6 +451,21 @@ inline bool expand_oligo(const Planes &w, std::vector<std::vector<uint8_t> > &ou
 	return true;
 }
 
+// glibc rand_r (stdlib/rand_r.c, glibc 2.35): the reference's only random source (sample.cpp:12,
+// pcr_assay.cpp:618-638, main.cpp:542).  Restated so that the sampler does not depend on the host libc.
+inline uint32_t rand_r_glibc(uint32_t *seed)
+{
+	uint32_t next = *seed;
+	next = next*1103515245u + 12345u;
+	uint32_t result = (next/65536u) % 2048u;
+	next = next*1103515245u + 12345u;
+	result = (result << 10) ^ ((next/65536u) % 1024u);
+	next = next*1103515245u + 12345u;
+	result = (result << 10) ^ ((next/65536u) % 1024u);
+	*seed = next;
+	return result;
+}
+
 // Word::degeneracy() (word.h:97-138): product of the slot multiplicities, in double
 inline double planes_degeneracy(const Planes &w)
 {

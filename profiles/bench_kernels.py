@@ -3,7 +3,9 @@
 out, so PCIe and launch overhead are included -- end-to-end per call, not kernel-only):
   * Smith-Waterman (pcr_sw_align_words, SeqOverlap lanes): GCUPS, cells = |q| x |t| per lane
   * thermodynamics (pcr_thermo = PCR::is_valid incl. hairpin + homodimer): oligos/s
+  * thermodynamics, small batch (the latency the local search and the sampler see): seconds per call of 64 oligos
   * local-search move evaluation (pcr_move_coverage): trial words/s at C2 scale
+  * random assay sampler (pcr_random_assays): trials/s on the C2 targets, with the CPU oracle beside it
 Prints one JSON object.  python profiles/bench_kernels.py"""
 import json
 import os
@@ -48,6 +50,10 @@ def main():
     scr.is_valid(ol, True)
     dt = time.perf_counter() - t0
     out["thermo"] = {"oligos": m, "seconds_per_call": dt, "oligos_per_s": m / dt}
+    t0 = time.perf_counter()
+    for k in range(50):
+        scr.is_valid(ol[64 * k:64 * k + 64], True)
+    out["thermo_small_batch"] = {"oligos": 64, "seconds_per_call": (time.perf_counter() - t0) / 50}
     # ---- move evaluation at C2 scale: all +degeneracy trials of one oligo (~60) in one call
     wl = synth.workload("C2", 0, 1.0)
     scr.load_sequences(wl["packed"], wl["byte_offsets"], wl["lengths"])
@@ -63,6 +69,27 @@ def main():
     dt = (time.perf_counter() - t0) / reps
     out["move_coverage"] = {"trials_per_call": len(trials), "targets": wl["T"], "seconds_per_call": dt,
                             "trial_x_target_evals_per_s": len(trials) * wl["T"] / dt}
+    # ---- sampler: 1000 trial assays on one running rand_r state (main.cpp:544-550 at one thread)
+    scr.random_assays(1, 20)
+    t0 = time.perf_counter()
+    pairs, _, info = scr.random_assays(7, 1000)
+    dt = time.perf_counter() - t0
+    out["sampler"] = {"trials": 1000, "seconds": dt, "trials_per_s": 1000 / dt,
+                      "mean_attempts": sum(i["assay_iterations"] for i in info) / 1000.0}
+    try:                                                               # CPU oracle beside it (checker, not product)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from oracle_lib import Oracle, random_assays
+        orc = Oracle()
+        so = orc.session()
+        for i in range(wl["T"]):
+            lo = int(wl["byte_offsets"][i])
+            so.add_target_packed(wl["packed"][lo:lo + (int(wl["lengths"][i]) + 1) // 2], int(wl["lengths"][i]))
+        t0 = time.perf_counter()
+        want, _ = random_assays(orc, so, 7, 1000)
+        out["sampler"]["cpu_oracle_seconds"] = time.perf_counter() - t0
+        out["sampler"]["matches_oracle"] = bool(want == pairs)
+    except Exception as e:                                             # noqa: BLE001
+        out["sampler"]["cpu_oracle_error"] = str(e)
     scr.close()
     print(json.dumps(out))
 

@@ -305,6 +305,42 @@ def optimize(lib, target_session, background_session, pair, moves=(0, 1, 2, 4, 3
     return ((int(flat[0]), int(flat[1])), (int(flat[2]), int(flat[3]))), tuple(float(x) for x in sc)
 
 
+class SamplerOptions(C.Structure):
+    _fields_ = [("primer_min", C.c_int), ("primer_max", C.c_int), ("amp_min", C.c_int), ("amp_max", C.c_int),
+                ("max_degen", C.c_double), ("salt", C.c_float), ("primer_strand", C.c_float), ("tm_min", C.c_float),
+                ("tm_max", C.c_float), ("max_hairpin", C.c_float), ("max_dimer", C.c_float)]
+
+
+DEFAULT_SAMPLER_OPTIONS = dict(primer_min=18, primer_max=25, amp_min=80, amp_max=200, max_degen=1.0, salt=0.05,
+                               primer_strand=9.0e-7, tm_min=50.0, tm_max=70.0, max_hairpin=40.0, max_dimer=40.0)
+
+
+def rand_r(lib, seed):
+    """glibc rand_r -> (value, next seed)."""
+    s = C.c_uint(seed)
+    fn = getattr(lib.lib, lib.prefix + "rand_r")
+    fn.restype = C.c_uint
+    fn.argtypes = [C.POINTER(C.c_uint)]
+    return fn(C.byref(s)), s.value
+
+
+def random_assays(lib, session, seed, n_trials, **so):
+    """PCR::random_assay x n_trials on one running seed (main.cpp:544-550 at one thread)
+    -> ([(F, R)], seed afterwards)."""
+    o = dict(DEFAULT_SAMPLER_OPTIONS)
+    o.update(so)
+    opts = SamplerOptions(**o)
+    out = np.zeros((n_trials, 4), dtype=np.uint64)
+    s = C.c_uint(seed)
+    fn = getattr(lib.lib, lib.prefix + "random_assays")
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.POINTER(C.c_uint), C.c_uint, C.POINTER(SamplerOptions), C.c_void_p]
+    rc = fn(session.h, C.byref(s), n_trials, C.byref(opts), out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(session.f("session_error")(session.h))
+    return [((int(r[0]), int(r[1])), (int(r[2]), int(r[3]))) for r in out], s.value
+
+
 def pairs_array(pairs):
     """pairs: list of (F, R) with F, R = (u64, u64) -> contiguous uint64 [n, 4]."""
     a = np.zeros((len(pairs), 4), dtype=np.uint64)

@@ -114,3 +114,23 @@ def test_moves_golden(ci):
             assert tuple(float(x) for x in s) == tuple(float(np.float32(x)) for x in sc), pi
     finally:
         d.close()
+
+
+@pytest.mark.parametrize("ci", range(4))
+def test_sampler_golden(ci):
+    """pcr_random_assays against tests/golden/sampler.json (the reference's PCR::random_assay on a running
+    rand_r state): the same assays and the same state afterwards."""
+    with open(os.path.join(G, "sampler.json")) as f:
+        c = json.load(f)["cases"][ci]
+    d = api.Screener(0)
+    try:
+        d.load_texts(c["seqs"], [1.0] * len(c["seqs"]))
+        d.set_active([bool(a) for a in c["active"]])
+        for i, pos in c["splits"]:
+            d.split(i, pos)
+        for seed, pairs, after in c["runs"]:
+            got, s, _ = d.random_assays(seed, len(pairs), **c["sampler_options"])
+            assert got == [((int(p[0], 16), int(p[1], 16)), (int(p[2], 16), int(p[3], 16))) for p in pairs], seed
+            assert s == after, seed
+    finally:
+        d.close()

@@ -205,3 +205,25 @@ def test_center_and_degeneracy_helpers_match_oracle(oracle):
         assert W.center_word(w) == oracle.word_center(w)
         assert W.word_degeneracy(w) == oracle.word_degeneracy(w)
     assert W.center_word((0, 0)) == (0, 0)
+
+
+def test_host_rand_r_is_glibc_rand_r():
+    """pcr_host_rand_r against this host's libc and the values the reference's libc produced (golden)."""
+    import ctypes
+    import json
+    import os
+    libc = ctypes.CDLL("libc.so.6")
+    for seed in (0, 1, 99, 0x7fffffff, 0x80000001, 0xffffffff):
+        st = ctypes.c_uint(seed)
+        s = seed
+        for _ in range(5):
+            v = libc.rand_r(ctypes.byref(st))
+            got, s = api.host_rand_r(s)
+            assert (got, s) == (v, st.value)
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sampler.json")) as f:
+        for seed, vals, after in json.load(f)["rand_r"]:
+            s = seed
+            for v in vals:
+                got, s = api.host_rand_r(s)
+                assert got == v
+            assert s == after

@@ -114,3 +114,41 @@ def test_moves(oracle, ci):
         got = optimize(oracle, ts, bs, pairs[pi], **c["move_options"])
         assert got[0] == ((int(bp[0], 16), int(bp[1], 16)), (int(bp[2], 16), int(bp[3], 16)))
         assert got[1] == tuple(float(np.float32(x)) for x in sc)
+
+
+def _sampler_session(lib, c):
+    sess = lib.session()
+    for q, a in zip(c["seqs"], c["active"]):
+        sess.add_target(q, 1.0, a)
+    for i, pos in c["splits"]:
+        sess.split(i, pos)
+    return sess
+
+
+def test_rand_r(oracle):
+    """glibc rand_r as the reference's libc produced it (golden) and as this host's libc does."""
+    import ctypes
+    from oracle_lib import rand_r
+    for seed, vals, after in load("sampler")["rand_r"]:
+        s = seed
+        for v in vals:
+            got, s = rand_r(oracle, s)
+            assert got == v
+        assert s == after
+    libc = ctypes.CDLL("libc.so.6")
+    for seed in (0, 5, 123456789, 0x80000000, 0xfffffffe):
+        st = ctypes.c_uint(seed)
+        v = libc.rand_r(ctypes.byref(st))
+        assert rand_r(oracle, seed) == (v, st.value)
+
+
+@pytest.mark.parametrize("ci", range(4))
+def test_sampler(oracle, ci):
+    """PCR::random_assay on a running rand_r state (the reference's own output): assays and final state."""
+    from oracle_lib import random_assays
+    c = load("sampler")["cases"][ci]
+    sess = _sampler_session(oracle, c)
+    for seed, pairs, after in c["runs"]:
+        got, s = random_assays(oracle, sess, seed, len(pairs), **c["sampler_options"])
+        assert got == [((int(p[0], 16), int(p[1], 16)), (int(p[2], 16), int(p[3], 16))) for p in pairs], seed
+        assert s == after, seed

@@ -454,3 +454,50 @@ def test_optimize_loop(oracle, reference, case):
         assert ro == rr, (p, ro, rr)
         changed += ro[0] != p
     assert changed > 0
+
+
+@pytest.mark.parametrize("case", [dict(), dict(max_degen=8.0, tm_min=40.0, tm_max=80.0), dict(tm_min=57.0, tm_max=61.0, max_hairpin=30.0),
+                                  dict(primer_min=20, primer_max=32, amp_min=70, amp_max=90, tm_min=55.0, tm_max=90.0),
+                                  dict(primer_min=18, primer_max=22, amp_min=38, amp_max=60, tm_min=40.0, tm_max=80.0)])
+def test_random_assays(oracle, reference, case):
+    """The reference's PCR::random_assay (one NucCruc, one running rand_r state, as main.cpp:544-550 at one
+    thread) against the oracle's restatement: same assays, same state afterwards, over many seeds."""
+    from oracle_lib import random_assays, rand_r
+    rng = random.Random(31 + len(case))
+    if case.get("amp_min") == 38:
+        seqs = [rand_seq(rng, n) for n in (40, 43, 52, 66, 90)]
+    else:
+        seqs = family_targets(rng, 3, 6, 800, div=0.05) + [rand_seq(rng, 301)]
+        q = list(seqs[3])
+        for k in range(200, 380, 7):
+            q[k] = rng.choice("RYKMSWBN")
+        seqs[3] = "".join(q)
+    so, sr = oracle.session(), reference.session()
+    for i, q in enumerate(seqs):
+        so.add_target(q, 1.0, i != 2)
+        sr.add_target(q, 1.0, i != 2)
+    if len(seqs) > 6:
+        for i, pos in ((1, 420), (6, 90), (6, 600)):
+            so.split(i, pos)
+            sr.split(i, pos)
+    for seed in range(60):
+        assert rand_r(oracle, seed * 2654435761 % 2**32) == rand_r(reference, seed * 2654435761 % 2**32)
+        assert random_assays(oracle, so, seed, 8, **case) == random_assays(reference, sr, seed, 8, **case), seed
+
+
+def test_random_assay_errors(oracle, reference):
+    """Where the reference throws, so does the oracle (same text)."""
+    from oracle_lib import random_assays
+    for lib in (oracle, reference):
+        s = lib.session()
+        s.add_target("ACGT" * 10, 1.0, True)
+        with pytest.raises(RuntimeError, match="sequence length is too small"):
+            random_assays(lib, s, 1, 1)
+        s = lib.session()
+        s.add_target("ACGT" * 100, 1.0, False)
+        with pytest.raises(RuntimeError, match="No active sequences"):
+            random_assays(lib, s, 1, 1)
+        s = lib.session()
+        s.add_target("A" * 400, 1.0, True)                             # nothing passes the Tm filter
+        with pytest.raises(RuntimeError, match="Unable to generate"):
+            random_assays(lib, s, 1, 1)
