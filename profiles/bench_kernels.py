@@ -5,6 +5,8 @@ out, so PCIe and launch overhead are included -- end-to-end per call, not kernel
   * thermodynamics (pcr_thermo = PCR::is_valid incl. hairpin + homodimer): oligos/s
   * thermodynamics, small batch (the latency the local search and the sampler see): seconds per call of 64 oligos
   * local-search move evaluation (pcr_move_coverage): trial words/s at C2 scale
+  * the optimize() loop of the local search (pcramp_amd.moves.optimize) on C2 targets + 2 000 backgrounds: seconds per
+    assay, with the CPU oracle's loop beside it on the same sessions
   * random assay sampler (pcr_random_assays): trials/s on the C2 targets, with the CPU oracle beside it
 Prints one JSON object.  python profiles/bench_kernels.py"""
 import json
@@ -69,6 +71,22 @@ def main():
     dt = (time.perf_counter() - t0) / reps
     out["move_coverage"] = {"trials_per_call": len(trials), "targets": wl["T"], "seconds_per_call": dt,
                             "trial_x_target_evals_per_s": len(trials) * wl["T"] / dt}
+    # ---- the whole optimize() loop for a few of the trial assays (targets + a background set)
+    try:
+        from pcramp_amd import moves
+        nb = 2000
+        bsel = slice(0, int(wl["byte_offsets"][nb]))
+        scr.load_sequences(wl["packed"][bsel], wl["byte_offsets"][:nb], wl["lengths"][:nb], which=api.BACKGROUND)
+        bthr = float(np.float32(0.8) * np.float32(0.9))
+        scr.select_words(wl["pairs"], bthr, 16, True, True, which=api.BACKGROUND)
+        kw = dict(degen=16, target_threshold=1.0, search_multiplier=0.9, amp_min=80, amp_max=200)
+        moves.optimize(scr, wl["pairs"][0], **kw)
+        t0 = time.perf_counter()
+        res = [moves.optimize(scr, pp, **kw) for pp in wl["pairs"][:8]]
+        dt = (time.perf_counter() - t0) / 8
+        out["optimize_loop"] = {"assays": 8, "targets": wl["T"], "backgrounds": nb, "seconds_per_assay": dt}
+    except Exception as e:                                             # noqa: BLE001
+        out["optimize_loop"] = {"error": str(e)}
     # ---- sampler: 1000 trial assays on one running rand_r state (main.cpp:544-550 at one thread)
     scr.random_assays(1, 20)
     t0 = time.perf_counter()
