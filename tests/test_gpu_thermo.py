@@ -115,3 +115,28 @@ def test_known_values(dev, oracle):
 def test_bad_oligo_rejected(dev, oracle):
     with pytest.raises(api.PcrError):
         dev.is_valid([(0, 0)])
+
+
+def test_both_kernel_forms_agree(dev, oracle):
+    """pcr_thermo / pcr_dimer pick the one-job-per-wave kernel for batches up to 20 480 jobs and the
+    64-jobs-per-wave kernel beyond: the same oligos through both (one big call vs. small calls) give the same
+    bits, and a sample of them equals the oracle."""
+    rng = random.Random(88)
+    seqs = []
+    for _ in range(1200):
+        n = rng.randint(12, 32)
+        seqs.append(rand_seq(rng, n) if rng.random() < 0.7 else hairpin_prone(rng, n)[:32])
+    words = [oracle.centered_word(s) for s in seqs]
+    small = dev.is_valid(words, True)                                  # 1 200 jobs: wave form
+    big = dev.is_valid(words * 20, True)                               # 24 000 jobs: 64-per-wave form
+    for k in range(20):
+        assert big[k * 1200:(k + 1) * 1200] == small
+    for s, r in list(zip(seqs, small))[::25]:
+        o = oracle.thermo_full(s, 0.05, 9e-7)
+        assert [r["tm"], r["dH"], r["dS"], r["hairpin_tm"], r["homodimer_tm"]] == [o[0], o[1], o[2], o[4], o[7]], s
+    pairs = [(words[i], words[(7 * i + 3) % 1200]) for i in range(1200)]
+    d_small = dev.max_dimer_tm(pairs)
+    d_big = dev.max_dimer_tm(pairs * 20)
+    assert np.array_equal(np.tile(d_small, 20), d_big)
+    for (a, b), d in list(zip(pairs, d_small))[::40]:
+        assert np.float32(oracle.max_dimer_tm((a, b))) == d
