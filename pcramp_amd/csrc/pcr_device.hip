@@ -599,6 +599,7 @@ struct pcr_ctx {
 	DevBuf<SwJob> sw_jobs; DevBuf<SwOut> sw_out; DevBuf<uint8_t> sw_q, sw_qlen, sw_t, entry_codes, entry_lens;
 	DevBuf<AmpRec> amp_recs; DevBuf<BgPairDev> bg_pairs;
 	DevBuf<thermo::Job> th_jobs; DevBuf<thermo::JobOut> th_out; DevBuf<int> th_dg, th_scratch_i; DevBuf<unsigned short> th_scratch_s;
+	float th_dg_salt = -1.0f;   // salt the table in th_dg was built for
 	size_t amp_cap = size_t(1) << 20;
 	uint32_t n_cu = 256;        // compute units of the device (hipDeviceProp)
 	uint32_t bucket_cap = 64;   // hit slots per sequence (grows on overflow)
@@ -617,6 +618,11 @@ struct pcr_ctx {
 	static constexpr uint32_t MAIL_RING = 8;
 	Mail *mail = nullptr, *mail_dev = nullptr;   // host-mapped ring (slot = seq % MAIL_RING): k_publish writes it, the host spins on seq
 	uint32_t mail_seq = 0;
+	// results of the small synchronous calls (move coverage, thermodynamics) come back the same way: a kernel
+	// copies them into a host-mapped buffer and raises a flag the host spins on (no copy-engine packets, no
+	// interrupt wake-up; three pageable hipMemcpyAsync + a stream sync cost ~1.8 ms per call instead)
+	uint8_t *ret_host = nullptr, *ret_dev = nullptr; size_t ret_cap = 0;
+	uint32_t *ret_flag = nullptr, *ret_flag_dev = nullptr; uint32_t ret_seq = 0;
 	// passes enqueued by pcr_screen_device whose counters have not been looked at yet (pcr_synchronize / any
 	// other entry point drains them; a bucket overflow found then replays the passes synchronously)
 	struct Pending {
@@ -823,6 +829,66 @@ int mail_wait(pcr_ctx *ctx, uint32_t seq, uint32_t out[4])
 		}
 	}
 	for(int i = 0;i < 4;++i) out[i] = slot->counters[i];
+	return PCR_OK;
+}
+
+// ---- small results back to the host through mapped memory (see pcr_ctx::ret_host)
+__global__ void k_return(const uint4 *__restrict__ s0, uint32_t n0, const uint4 *__restrict__ s1, uint32_t n1,
+	const uint4 *__restrict__ s2, uint32_t n2, uint4 *__restrict__ dst)
+{
+	const uint32_t stride = gridDim.x*blockDim.x, t = blockIdx.x*blockDim.x + threadIdx.x;
+	for(uint32_t i = t;i < n0;i += stride) dst[i] = s0[i];
+	for(uint32_t i = t;i < n1;i += stride) dst[n0 + i] = s1[i];
+	for(uint32_t i = t;i < n2;i += stride) dst[n0 + n1 + i] = s2[i];
+}
+
+__global__ void k_return_flag(uint32_t *flag, uint32_t seq)
+{
+	__threadfence_system();
+	__hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Copies up to three device regions (16-byte aligned; sizes are rounded UP to 16 bytes, so the buffers need that
+// slack) back to back into the mapped return buffer and waits for them.  out[k] = host address of region k.
+int return_to_host(pcr_ctx *ctx, const void *s0, size_t b0, const void *s1, size_t b1, const void *s2, size_t b2, const uint8_t *out[3])
+{
+	const uint32_t n0 = (uint32_t)((b0 + 15)/16), n1 = (uint32_t)((b1 + 15)/16), n2 = (uint32_t)((b2 + 15)/16);
+	const size_t need = ((size_t)n0 + n1 + n2)*16;
+	if(!ctx->ret_flag){
+		HIP_TRY(hipHostMalloc((void **)&ctx->ret_flag, 64, hipHostMallocMapped | hipHostMallocCoherent));
+		HIP_TRY(hipHostGetDevicePointer((void **)&ctx->ret_flag_dev, ctx->ret_flag, 0));
+		*ctx->ret_flag = 0;
+	}
+	if(need > ctx->ret_cap){
+		HIP_TRY(hipStreamSynchronize(ctx->stream));
+		if(ctx->ret_host){ (void)hipHostFree(ctx->ret_host); ctx->ret_host = nullptr; ctx->ret_cap = 0; }
+		const size_t want = std::max<size_t>(need*2, 1 << 20);
+		HIP_TRY(hipHostMalloc((void **)&ctx->ret_host, want, hipHostMallocMapped | hipHostMallocCoherent));
+		HIP_TRY(hipHostGetDevicePointer((void **)&ctx->ret_dev, ctx->ret_host, 0));
+		ctx->ret_cap = want;
+	}
+	const uint32_t most = std::max(n0, std::max(n1, n2));
+	if(most){
+		const unsigned grid = std::min<unsigned>((most + 255)/256, 1024u);
+		hipLaunchKernelGGL(k_return, dim3(grid), dim3(256), 0, ctx->stream, (const uint4 *)s0, n0, (const uint4 *)s1, n1, (const uint4 *)s2, n2, (uint4 *)ctx->ret_dev);
+		HIP_TRY(hipGetLastError());
+	}
+	const uint32_t seq = ++ctx->ret_seq;
+	hipLaunchKernelGGL(k_return_flag, dim3(1), dim3(1), 0, ctx->stream, ctx->ret_flag_dev, seq);
+	HIP_TRY(hipGetLastError());
+	uint64_t spins = 0;
+	while(__atomic_load_n((const uint32_t *)ctx->ret_flag, __ATOMIC_ACQUIRE) != seq){
+		__builtin_ia32_pause();
+		if((++spins & 0x3FFF) == 0){
+			const hipError_t e = hipStreamQuery(ctx->stream);
+			if(e == hipSuccess){
+				if(__atomic_load_n((const uint32_t *)ctx->ret_flag, __ATOMIC_ACQUIRE) == seq) break;
+				g_err = "device work finished without raising the return flag"; return PCR_ERR_DEVICE;
+			}
+			if(e != hipErrorNotReady){ g_err = std::string("device work failed: ") + hipGetErrorString(e); return PCR_ERR_DEVICE; }
+		}
+	}
+	out[0] = ctx->ret_host; out[1] = ctx->ret_host + (size_t)n0*16; out[2] = ctx->ret_host + ((size_t)n0 + n1)*16;
 	return PCR_OK;
 }
 
@@ -1045,6 +1111,8 @@ void pcr_destroy(pcr_ctx *ctx)
 	ctx->bits_fr.release(); ctx->bits_rf.release(); ctx->arena.release(); ctx->fin_scratch.release();
 	for(auto &sl : ctx->stage){ if(sl.host) (void)hipHostFree(sl.host); if(sl.done) (void)hipEventDestroy(sl.done); }
 	if(ctx->mail) (void)hipHostFree(ctx->mail);
+	if(ctx->ret_host) (void)hipHostFree(ctx->ret_host);
+	if(ctx->ret_flag) (void)hipHostFree(ctx->ret_flag);
 	ctx->oligos.release(); ctx->sw_jobs.release(); ctx->sw_out.release(); ctx->sw_q.release(); ctx->sw_qlen.release(); ctx->sw_t.release(); ctx->entry_codes.release(); ctx->entry_lens.release(); ctx->amp_recs.release(); ctx->bg_pairs.release(); ctx->th_jobs.release(); ctx->th_out.release(); ctx->th_dg.release(); ctx->th_scratch_i.release(); ctx->th_scratch_s.release();
 	if(ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
@@ -1759,18 +1827,14 @@ int pcr_move_coverage(pcr_ctx *ctx, pcr_set which, const pcr_pair *base, int sid
 		d_ol, d_ol + 2, n_variants, side, S.planes.p, S.d_blk_off.p, S.d_len.p, S.d_active.p, args->amp_min, args->amp_max,
 		args->ident_threshold, args->use_taq_mama, ctx->bits_fr.p, ctx->bits_rf.p, words, ctx->status.p);
 	HIP_TRY(hipGetLastError());
-	std::vector<uint64_t> hfr(total), hrf(total);
-	uint32_t status = 0;
-	HIP_TRY(hipMemcpyAsync(hfr.data(), ctx->bits_fr.p, total*sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-	HIP_TRY(hipMemcpyAsync(hrf.data(), ctx->bits_rf.p, total*sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-	HIP_TRY(hipMemcpyAsync(&status, ctx->status.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	const uint8_t *back[3];
+	if((rc = return_to_host(ctx, ctx->bits_fr.p, total*sizeof(uint64_t), ctx->bits_rf.p, total*sizeof(uint64_t), ctx->status.p, sizeof(uint32_t), back)) != PCR_OK) return rc;
+	const uint64_t *hfr = (const uint64_t *)back[0], *hrf = (const uint64_t *)back[1];
+	const uint32_t status = *(const uint32_t *)back[2];
 	if(status & 1u){ g_err = "Sequence::has_split: range is out of bounds"; return PCR_ERR_RANGE; }   // sequence.cpp:306-308
-	for(uint32_t v = 0;v < n_variants;++v){
-		if(bits_fr) memcpy(bits_fr + v*words, hfr.data() + v*words, words*sizeof(uint64_t));
-		if(bits_rf) memcpy(bits_rf + v*words, hrf.data() + v*words, words*sizeof(uint64_t));
-		if(coverage) coverage[v] = pcr_coverage_from_bits(hfr.data() + v*words, hrf.data() + v*words, S.weight.data(), S.n);
-	}
+	if(bits_fr) memcpy(bits_fr, hfr, total*sizeof(uint64_t));
+	if(bits_rf) memcpy(bits_rf, hrf, total*sizeof(uint64_t));
+	if(coverage){ for(uint32_t v = 0;v < n_variants;++v) coverage[v] = pcr_coverage_from_bits(hfr + v*words, hrf + v*words, S.weight.data(), S.n); }
 	return PCR_OK;
 }
 
@@ -1779,9 +1843,12 @@ float pcr_coverage_from_bits(const uint64_t *bits_fr, const uint64_t *bits_rf, c
 	// PCR::compute_coverage (pcr_assay.cpp:271-302): amplicons are visited {F(+),R(-)} first in
 	// ascending sequence order, then {R(+),F(-)}; each sequence's weight is added once, in double.
 	double ret = 0.0;
-	for(uint64_t i = 0;i < n;++i){ if((bits_fr[i >> 6] >> (i & 63)) & 1) ret += weights[i]; }
-	for(uint64_t i = 0;i < n;++i){
-		if(((bits_rf[i >> 6] >> (i & 63)) & 1) && !((bits_fr[i >> 6] >> (i & 63)) & 1)) ret += weights[i];
+	const uint64_t nw = (n + 63)/64;
+	for(uint64_t w = 0;w < nw;++w){                                               // set bits in ascending order
+		for(uint64_t m = bits_fr[w];m;m &= m - 1){ const uint64_t i = w*64 + (uint64_t)__builtin_ctzll(m); if(i < n) ret += weights[i]; }
+	}
+	for(uint64_t w = 0;w < nw;++w){
+		for(uint64_t m = bits_rf[w] & ~bits_fr[w];m;m &= m - 1){ const uint64_t i = w*64 + (uint64_t)__builtin_ctzll(m); if(i < n) ret += weights[i]; }
 	}
 	return (float)ret;
 }
@@ -1789,7 +1856,10 @@ float pcr_coverage_from_bits(const uint64_t *bits_fr, const uint64_t *bits_rf, c
 float pcr_weighted_coverage(const uint64_t *bits, const float *weights, uint64_t n)
 {
 	double ret = 0.0;                                                            // main.cpp:1402-1418
-	for(uint64_t i = 0;i < n;++i){ if((bits[i >> 6] >> (i & 63)) & 1) ret += weights[i]; }
+	const uint64_t nw = (n + 63)/64;
+	for(uint64_t w = 0;w < nw;++w){
+		for(uint64_t m = bits[w];m;m &= m - 1){ const uint64_t i = w*64 + (uint64_t)__builtin_ctzll(m); if(i < n) ret += weights[i]; }
+	}
 	return (float)ret;
 }
 
