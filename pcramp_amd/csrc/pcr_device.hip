@@ -560,6 +560,7 @@ struct SeqSet {
 	DevBuf<uint8_t> tile_degen; uint32_t n_degen_tiles = 0;
 	DevBuf<uint64_t> d_len, d_blk_off, d_nblk_real;
 	DevBuf<uint8_t> d_active;
+	std::vector<uint8_t> has_eos; DevBuf<uint8_t> d_has_eos;   // sequence holds an EOS nibble (record padding, splits): only then has_split has to look
 	DevBuf<IrrDev> irr;
 	DevBuf<uint8_t> codes; DevBuf<uint64_t> d_code_off; bool have_codes = false;
 	// word DB of the last select
@@ -577,7 +578,7 @@ struct SeqSet {
 	{
 		irr_perm.release(); planes.release(); valid.release(); nib.release(); tb.release(); degen_tiles.release(); tile_degen.release(); blk_seq.release(); tile_seq.release(); tile_pos0.release();
 		irr_off.release(); d_len.release(); d_blk_off.release();
-		d_nblk_real.release(); d_active.release(); irr.release(); db.release(); touched.release(); ctrl.release(); codes.release(); d_code_off.release();
+		d_nblk_real.release(); d_active.release(); d_has_eos.release(); irr.release(); db.release(); touched.release(); ctrl.release(); codes.release(); d_code_off.release();
 	}
 };
 
@@ -1147,6 +1148,7 @@ int pcr_load_sequences(pcr_ctx *ctx, pcr_set which, const uint8_t *packed4, cons
 	S.weight.assign(n, 1.0f);
 	if(weights) S.weight.assign(weights, weights + n);
 	S.active.assign(n, 1);
+	S.has_eos.assign(n, 0);
 	S.blk_off.assign(n + 1, 0);
 	S.nblk_real.assign(n, 0);
 	S.irr_host.assign(n, std::vector<pcrhost::IrrEntry>());
@@ -1157,6 +1159,14 @@ int pcr_load_sequences(pcr_ctx *ctx, pcr_set which, const uint8_t *packed4, cons
 		const uint64_t nb = (lengths[s] + 1)/2;
 		S.packed[s].assign(packed4 + byte_offsets[s], packed4 + byte_offsets[s] + nb);
 		if((lengths[s] & 1) && nb) S.packed[s][nb - 1] &= 0xF0;                  // pad nibble = EOS (sequence.cpp:21)
+		{
+			const std::vector<uint8_t> &b = S.packed[s];
+			bool eos = false;
+			const uint64_t full = lengths[s]/2;
+			for(uint64_t k = 0;k < full && !eos;++k) eos = ((b[k] & 0xF0) == 0) || ((b[k] & 0x0F) == 0);
+			if(!eos && (lengths[s] & 1)) eos = ((b[full] & 0xF0) == 0);
+			S.has_eos[s] = eos ? 1 : 0;
+		}
 		dev_byte_off[s] = total_bytes;
 		total_bytes += nb;
 		S.blk_off[s] = total_blocks;
@@ -1202,6 +1212,7 @@ int pcr_load_sequences(pcr_ctx *ctx, pcr_set which, const uint8_t *packed4, cons
 	if((rc = S.d_blk_off.ensure(n + 1)) != PCR_OK) return fail(rc);
 	if((rc = S.d_nblk_real.ensure(n)) != PCR_OK) return fail(rc);
 	if((rc = S.d_active.ensure(n)) != PCR_OK) return fail(rc);
+	if((rc = S.d_has_eos.ensure(n)) != PCR_OK) return fail(rc);
 #define H2D(dst, src, bytes) do{ if((bytes) > 0){ hipError_t e_ = hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice); \
 	if(e_ != hipSuccess){ g_err = std::string("hipMemcpy: ") + hipGetErrorString(e_); return fail(PCR_ERR_DEVICE); } } }while(0)
 	{   // one transfer for all sequences (a copy per sequence was 10 000 copy-engine packets at C2)
@@ -1217,6 +1228,7 @@ int pcr_load_sequences(pcr_ctx *ctx, pcr_set which, const uint8_t *packed4, cons
 	H2D(S.d_blk_off.p, S.blk_off.data(), (n + 1)*sizeof(uint64_t));
 	H2D(S.d_nblk_real.p, S.nblk_real.data(), n*sizeof(uint64_t));
 	H2D(S.d_active.p, S.active.data(), n);
+	H2D(S.d_has_eos.p, S.has_eos.data(), n);
 #undef H2D
 	if(total_blocks){
 		const unsigned threads = 256;
@@ -1269,6 +1281,7 @@ int pcr_split(pcr_ctx *ctx, pcr_set which, uint32_t seq, uint64_t pos)
 	if(seq >= S.n || pos >= S.len[seq]){ g_err = "pcr_split: out of range"; return PCR_ERR_ARG; }
 	uint8_t &v = S.packed[seq][pos >> 1];
 	v = (pos & 1) ? (v & 0xF0) : (v & 0x0F);                                     // sequence.h:232-241
+	if(!S.has_eos[seq]){ S.has_eos[seq] = 1; HIP_TRY(hipMemcpy(S.d_has_eos.p + seq, &S.has_eos[seq], 1, hipMemcpyHostToDevice)); }
 	// device: clear the base in its block, refresh the 2 blocks of windows that can see it, redo the irregular list
 	const uint64_t gb = S.blk_off[seq] + (pos >> 5);
 	uint4 blk;
@@ -1824,7 +1837,7 @@ int pcr_move_coverage(pcr_ctx *ctx, pcr_set which, const pcr_pair *base, int sid
 		S.touched.p, S.d_seg_hi, d_ol, 2u, 1u, ctx->mask.p, ctx->status.p, (const uint32_t *)nullptr, (PassMail *)nullptr, 0u);
 	HIP_TRY(hipGetLastError());
 	hipLaunchKernelGGL(k_pair_moves, dim3((n_db + 127)/128), dim3(128), 0, ctx->stream, S.db.p, n_db, S.db_cap, S.touched.p, S.d_seg_hi, ctx->mask.p,
-		d_ol, d_ol + 2, n_variants, side, S.planes.p, S.d_blk_off.p, S.d_len.p, S.d_active.p, args->amp_min, args->amp_max,
+		d_ol, d_ol + 2, n_variants, side, S.planes.p, S.d_blk_off.p, S.d_len.p, S.d_active.p, S.d_has_eos.p, args->amp_min, args->amp_max,
 		args->ident_threshold, args->use_taq_mama, ctx->bits_fr.p, ctx->bits_rf.p, words, ctx->status.p);
 	HIP_TRY(hipGetLastError());
 	const uint8_t *back[3];

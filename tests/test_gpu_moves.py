@@ -54,6 +54,56 @@ def test_move_coverage_matches_oracle(oracle, opts):
         d.close()
 
 
+def test_move_coverage_with_splits_and_inactive_sequences(oracle):
+    """EOS inside the candidate amplicons (has_split, sequence.cpp:304), record padding ('-'), inactive
+    sequences; wide amplicon range so that many partners are swept per site."""
+    o = dict(target_threshold=0.85, search_multiplier=0.9, amp_min=40, amp_max=600, use_taq_mama=0,
+             pack_max_degen=256, pack_min_gc=0.0, pack_max_gc=1.0, min_primer=18, optimize_5=0, optimize_3=0)
+    rng = random.Random(4711)
+    seqs = family_targets(rng, 3, 8, 900, div=0.06)
+    pairs_txt = []
+    while len(pairs_txt) < 6:
+        p = sample_pair(rng, rng.choice(seqs))
+        if p:
+            pairs_txt.append(p)
+    seqs[3] = seqs[3][:450] + "----" + seqs[3][454:]                  # multi-record padding
+    pairs = [(oracle.centered_word(f), oracle.centered_word(r)) for f, r in pairs_txt]
+    so = oracle.session(**o)
+    for s in seqs:
+        so.add_target(s, 1.0)
+    d = api.Screener(0)
+    try:
+        d.load_texts(seqs, [1.0] * len(seqs))
+        active = [i % 5 != 2 for i in range(len(seqs))]
+        d.set_active(active)
+        for i, a in enumerate(active):
+            so.set_active(i, a)
+        for i in range(0, len(seqs), 3):                               # a split somewhere inside every third sequence
+            pos = 150 + 29 * i
+            so.split(i, pos)
+            d.split(i, pos)
+        thr = float(np.float32(o["target_threshold"]) * np.float32(o["search_multiplier"]))
+        so.select(pairs)
+        d.select_words(pairs, thr, o["min_primer"])
+        nonzero = zero = 0
+        for p in pairs:
+            for side in (0, 1):
+                var = [p[side]]
+                for kind in ("inc", "trim5", "trim3", "grow5", "grow3"):
+                    var += move_variants(W, p[side], kind)
+                co, oo = so.move_coverage(p, side, var, orient=True)
+                cd, fr, rf = d.move_coverage(p, side, var, o["target_threshold"], o["search_multiplier"], o["amp_min"],
+                                             o["amp_max"], False)
+                assert np.array_equal(cd, co)
+                assert np.array_equal(fr, (oo & 1) != 0)
+                assert np.array_equal(rf, (oo & 2) != 0)
+                nonzero += int(np.count_nonzero(co))
+                zero += int(np.count_nonzero(co == 0))
+        assert nonzero > 50, (nonzero, zero)
+    finally:
+        d.close()
+
+
 def test_move_coverage_of_the_base_word_is_compute_coverage(oracle):
     """The unedited oligo as its own 'variant' gives compute_coverage of the pair."""
     rng = random.Random(5)
