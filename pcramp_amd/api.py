@@ -373,19 +373,24 @@ class Screener:
                                              C.c_void_p(d_fr_ptr), C.c_void_p(d_rf_ptr)))
 
     def move_coverage(self, base_pair, side, variants, target_threshold=1.0, search_multiplier=0.9, amp_min=80, amp_max=200,
-                      use_taq_mama=False, which=TARGET):
+                      use_taq_mama=False, which=TARGET, bits=True):
         """optimize_pcr.cpp move evaluation: every variant of one oligo (side 0 = F, 1 = R) over the base pair's
-        candidate amplicons -> (coverage float32[n_variants], bits_fr bool[n_variants, n], bits_rf)."""
+        candidate amplicons -> (coverage float32[n_variants], bits_fr bool[n_variants, n], bits_rf);
+        bits=False skips the per-sequence bitsets (None, None)."""
         a = W.pairs_array([base_pair])
         v = np.array([[int(w[0]), int(w[1])] for w in variants], dtype=np.uint64).reshape(-1, 2)
         V = v.shape[0]
+        cov = np.zeros(max(V, 1), np.float32)
+        ct = float(np.float32(target_threshold) * np.float32(search_multiplier))
+        args = AmplifyArgs(ct, target_threshold, amp_min, amp_max, int(use_taq_mama))
+        if not bits:
+            self._check(self.L.pcr_move_coverage(self.h, which, a.ctypes.data, int(side), v.ctypes.data, V, C.byref(args),
+                                                 None, None, cov.ctypes.data))
+            return cov[:V], None, None
         nw = int(self.bitset_words(which))
         n = self.num_sequences(which)
         fr = np.zeros((max(V, 1), nw), np.uint64)
         rf = np.zeros((max(V, 1), nw), np.uint64)
-        cov = np.zeros(max(V, 1), np.float32)
-        ct = float(np.float32(target_threshold) * np.float32(search_multiplier))
-        args = AmplifyArgs(ct, target_threshold, amp_min, amp_max, int(use_taq_mama))
         self._check(self.L.pcr_move_coverage(self.h, which, a.ctypes.data, int(side), v.ctypes.data, V, C.byref(args),
                                              fr.ctypes.data, rf.ctypes.data, cov.ctypes.data))
         tb = lambda x: np.stack([bits_to_bool(x[i], n) for i in range(V)]) if V else np.zeros((0, n), bool)
@@ -439,12 +444,15 @@ class Screener:
         return ThermoArgs(salt, primer_strand, tm_min, tm_max, max_hairpin, max_dimer)
 
     def is_valid(self, oligos, check_homo_dimer=True, salt=0.05, primer_strand=9e-7, tm_min=50.0, tm_max=75.0,
-                 max_hairpin=40.0, max_dimer=40.0):
-        """PCR::is_valid for a batch of oligo words -> list of ThermoResult-like dicts."""
+                 max_hairpin=40.0, max_dimer=40.0, flags=False):
+        """PCR::is_valid for a batch of oligo words -> list of ThermoResult-like dicts (flags=True: only the
+        pass/fail bools, as an array)."""
         a = np.array([[w[0], w[1]] for w in oligos], dtype=np.uint64).reshape(-1, 2)
         out = (ThermoResult * max(len(oligos), 1))()
         args = self._targs(salt, primer_strand, tm_min, tm_max, max_hairpin, max_dimer)
         self._check(self.L.pcr_thermo(self.h, a.ctypes.data, len(oligos), int(check_homo_dimer), C.byref(args), out))
+        if flags:
+            return np.frombuffer(out, dtype=np.uint32).reshape(-1, 8)[:len(oligos), 0] != 0
         return [dict(valid=bool(r.valid), n=r.n_expansions, tm=np.float32(r.tm), dH=np.float32(r.dH), dS=np.float32(r.dS),
                      hairpin_tm=np.float32(r.hairpin_tm), homodimer_tm=np.float32(r.homodimer_tm)) for r in out[:len(oligos)]]
 

@@ -1833,8 +1833,8 @@ int pcr_move_coverage(pcr_ctx *ctx, pcr_set which, const pcr_pair *base, int sid
 	if((rc = ctx->mask.ensure((size_t)S.n_slots)) != PCR_OK) return rc;
 	if((rc = ctx->status.ensure(1)) != PCR_OK) return rc;
 	const uint32_t n_db = S.n_touched*S.db_cap;
-	hipLaunchKernelGGL(k_match, dim3((S.n_touched + MATCH_WAVES - 1)/MATCH_WAVES), dim3(64*MATCH_WAVES), 0, ctx->stream, S.db.p, S.n_touched, (const uint32_t *)nullptr, S.db_cap,
-		S.touched.p, S.d_seg_hi, d_ol, 2u, 1u, ctx->mask.p, ctx->status.p, (const uint32_t *)nullptr, (PassMail *)nullptr, 0u);
+	hipLaunchKernelGGL(k_match_few, dim3((n_db + 255)/256), dim3(256), 0, ctx->stream, S.db.p, n_db, S.db_cap, S.touched.p, S.d_seg_hi, d_ol, 2u,
+		ctx->mask.p, ctx->status.p);
 	HIP_TRY(hipGetLastError());
 	hipLaunchKernelGGL(k_pair_moves, dim3((n_db + 127)/128), dim3(128), 0, ctx->stream, S.db.p, n_db, S.db_cap, S.touched.p, S.d_seg_hi, ctx->mask.p,
 		d_ol, d_ol + 2, n_variants, side, S.planes.p, S.d_blk_off.p, S.d_len.p, S.d_active.p, S.d_has_eos.p, args->amp_min, args->amp_max,

@@ -32,11 +32,11 @@ def base_score(scr, pair, target_threshold=1.0, search_multiplier=0.9, amp_min=8
                bg_threshold=0.8, bg_multiplier=0.9, bg_amp_min=0, bg_amp_max=2000, have_background=True):
     """(target_coverage, background_coverage) of the unmodified assay, optimize.cpp:72-76."""
     tc, _, _ = scr.move_coverage(pair, 0, [pair[0]], target_threshold, search_multiplier, amp_min, amp_max, use_taq_mama,
-                                 which=api.TARGET)
+                                 which=api.TARGET, bits=False)
     bc = np.float32(0.0)
     if have_background:
         b, _, _ = scr.move_coverage(pair, 0, [pair[0]], bg_threshold, bg_multiplier, bg_amp_min, bg_amp_max, use_taq_mama,
-                                    which=api.BACKGROUND)
+                                    which=api.BACKGROUND, bits=False)
         bc = b[0]
     return np.float32(tc[0]), np.float32(bc)
 
@@ -59,15 +59,15 @@ def optimization_move(scr, pair, move, side, score_threshold=None, degen=1, prim
     if not trials:
         return best_w, best
     ok = scr.is_valid(trials, check_homo_dimer=False, salt=salt, primer_strand=primer_strand, tm_min=tm_min, tm_max=tm_max,
-                      max_hairpin=max_hairpin, max_dimer=0.0)
-    live = [t for t, r in zip(trials, ok) if r["valid"]]
+                      max_hairpin=max_hairpin, max_dimer=0.0, flags=True)
+    live = [t for t, v in zip(trials, ok) if v]
     if not live:
         return best_w, best
     tcov, _, _ = scr.move_coverage(pair, side, live, target_threshold, search_multiplier, amp_min, amp_max, use_taq_mama,
-                                   which=api.TARGET)
+                                   which=api.TARGET, bits=False)
     if have_background:
         bcov, _, _ = scr.move_coverage(pair, side, live, bg_threshold, bg_multiplier, bg_amp_min, bg_amp_max, use_taq_mama,
-                                       which=api.BACKGROUND)
+                                       which=api.BACKGROUND, bits=False)
     else:
         bcov = np.zeros(len(live), np.float32)
     for t, tc, bc in zip(live, tcov, bcov):
@@ -111,8 +111,8 @@ def _evaluate_iteration(scr, approx, move_list, degen=1, primer_min=18, primer_m
             per[(side, mv)] = (len(flat[side]), len(tr))
             flat[side] += tr
     allw = flat[0] + flat[1]
-    ok = [r["valid"] for r in scr.is_valid(allw, check_homo_dimer=False, salt=salt, primer_strand=primer_strand, tm_min=tm_min,
-                                           tm_max=tm_max, max_hairpin=max_hairpin, max_dimer=0.0)] if allw else []
+    ok = [bool(v) for v in scr.is_valid(allw, check_homo_dimer=False, salt=salt, primer_strand=primer_strand, tm_min=tm_min,
+                                        tm_max=tm_max, max_hairpin=max_hairpin, max_dimer=0.0, flags=True)] if allw else []
     out = {}
     base = 0
     for side in (0, 1):
@@ -123,10 +123,10 @@ def _evaluate_iteration(scr, approx, move_list, degen=1, primer_min=18, primer_m
         tcov = bcov = []
         if live:
             tcov, _, _ = scr.move_coverage(approx, side, live, target_threshold, search_multiplier, amp_min, amp_max, use_taq_mama,
-                                           which=api.TARGET)
+                                           which=api.TARGET, bits=False)
             if have_background:
                 bcov, _, _ = scr.move_coverage(approx, side, live, bg_threshold, bg_multiplier, bg_amp_min, bg_amp_max,
-                                               use_taq_mama, which=api.BACKGROUND)
+                                               use_taq_mama, which=api.BACKGROUND, bits=False)
             else:
                 bcov = np.zeros(len(live), np.float32)
         it = iter(zip(tcov, bcov))
