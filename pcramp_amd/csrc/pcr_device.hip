@@ -1778,23 +1778,22 @@ int pcr_amplify(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 	const uint64_t words = (S.n + 63)/64;
 	const size_t total = (size_t)n_pairs*words;
 	int rc;
-	if((rc = ctx->bits_fr.ensure(total)) != PCR_OK) return rc;
-	if((rc = ctx->bits_rf.ensure(total)) != PCR_OK) return rc;
+	if((rc = ctx->bits_fr.ensure(total + 2)) != PCR_OK) return rc;               // + 2: return_to_host copies whole 16-byte units
+	if((rc = ctx->bits_rf.ensure(total + 2)) != PCR_OK) return rc;
+	if((rc = ctx->status.ensure(1)) != PCR_OK) return rc;
 	if((rc = amplify_launch(ctx, S, pairs, n_pairs, args, ctx->bits_fr.p, ctx->bits_rf.p)) != PCR_OK) return rc;
-	std::vector<uint64_t> hfr(total), hrf(total);
-	uint32_t status = 0;
-	if(total){
-		HIP_TRY(hipMemcpyAsync(hfr.data(), ctx->bits_fr.p, total*sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-		HIP_TRY(hipMemcpyAsync(hrf.data(), ctx->bits_rf.p, total*sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-	}
-	if(ctx->status.p && S.n_entries && n_pairs) HIP_TRY(hipMemcpyAsync(&status, ctx->status.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	const bool have_status = S.n_entries && n_pairs;                             // the screen ran and wrote the status word
+	const uint8_t *back[3];
+	if((rc = return_to_host(ctx, ctx->bits_fr.p, total*sizeof(uint64_t), ctx->bits_rf.p, total*sizeof(uint64_t),
+		have_status ? ctx->status.p : nullptr, have_status ? sizeof(uint32_t) : 0, back)) != PCR_OK) return rc;
+	const uint64_t *hfr = (const uint64_t *)back[0], *hrf = (const uint64_t *)back[1];
+	const uint32_t status = have_status ? *(const uint32_t *)back[2] : 0u;
 	if(status & 1u){ g_err = "Sequence::has_split: range is out of bounds"; return PCR_ERR_RANGE; }   // sequence.cpp:306-308
 	for(uint32_t p = 0;p < n_pairs;++p){
 		if(bits){ for(uint64_t w = 0;w < words;++w) bits[p*words + w] = hfr[p*words + w] | hrf[p*words + w]; }
-		if(bits_fr) memcpy(bits_fr + p*words, hfr.data() + p*words, words*sizeof(uint64_t));
-		if(bits_rf) memcpy(bits_rf + p*words, hrf.data() + p*words, words*sizeof(uint64_t));
-		if(coverage) coverage[p] = pcr_coverage_from_bits(hfr.data() + p*words, hrf.data() + p*words, S.weight.data(), S.n);
+		if(bits_fr) memcpy(bits_fr + p*words, hfr + p*words, words*sizeof(uint64_t));
+		if(bits_rf) memcpy(bits_rf + p*words, hrf + p*words, words*sizeof(uint64_t));
+		if(coverage) coverage[p] = pcr_coverage_from_bits(hfr + p*words, hrf + p*words, S.weight.data(), S.n);
 	}
 	return PCR_OK;
 }
