@@ -274,6 +274,14 @@ typedef struct {
 int pcr_random_assays(pcr_ctx *ctx, pcr_set which, uint32_t *seed, uint32_t n_trials, const pcr_sampler_args *sampler,
 	const pcr_thermo_args *thermo, pcr_pair *pairs_out, pcr_sample_info *info_out);
 
+/* Word::max_overlap (word.h:38-91): the best ungapped diagonal of equal codes between two oligo words, as a
+ * fraction of the longer one -- the oligo-reuse term of the multiplex Score (pcramp.h:158-208).  Host arithmetic. */
+float pcr_host_max_overlap(const pcr_word128 *a, const pcr_word128 *b);
+
+/* PCR::compute_oligo_overlap (pcr_assay.cpp:736-754): both oligos of `assay` against both oligos of every pooled
+ * assay, with MULTIPLEX_OLIGO_REUSE_BONUS (assay.h:19) for an identical oligo.  Host arithmetic. */
+float pcr_host_oligo_overlap(const pcr_pair *assay, const pcr_pair *pool, uint32_t n_pool);
+
 /* glibc rand_r (the reference's random source, sample.cpp:12), restated; usable without a GPU. */
 uint32_t pcr_host_rand_r(uint32_t *seed);
 

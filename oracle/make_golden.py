@@ -299,13 +299,37 @@ def sampler_golden(ref):
     return {"rand_r": stream, "cases": cases}
 
 
+def overlap_golden(ref):
+    """Word::max_overlap and PCR::compute_oligo_overlap (the oligo-reuse term of the multiplex Score)."""
+    rng = random.Random(5150)
+    words = []
+    for _ in range(60):
+        w = ref.word(rand_seq(rng, rng.randint(15, 32), p_degen=0.15))
+        for _ in range(rng.randint(0, 5)):
+            w = ref.word_shift_right(w)
+        words.append(w)
+    base = rand_seq(rng, 30)
+    for k in range(8):                                                 # related words: shared stretches, identical copies
+        words.append(ref.centered_word(base[k:k + 18 + k]))
+    words.append(words[-1])
+    pairs = [[i, j, ref.max_overlap(words[i], words[j])] for i in range(len(words)) for j in range(0, len(words), 3)]
+    assays = []
+    for _ in range(40):
+        a = (rng.choice(words), rng.choice(words))
+        pool = [(rng.choice(words), rng.choice(words)) for _ in range(rng.randint(0, 6))]
+        assays.append({"assay": hexw(a[0]) + hexw(a[1]), "pool": [hexw(f) + hexw(r) for f, r in pool],
+                       "overlap": ref.oligo_overlap(a, pool)})
+    return {"words": [hexw(w) for w in words], "max_overlap": pairs, "oligo_overlap": assays}
+
+
 def main():
     build_reference()
     ref = Reference()
     os.makedirs(OUT, exist_ok=True)
     only = set(sys.argv[1:])
     for name, fn in (("words", words_golden), ("pack", pack_golden), ("screen", screen_golden), ("sw", sw_golden),
-                     ("thermo", thermo_golden), ("moves", moves_golden), ("sampler", sampler_golden)):
+                     ("thermo", thermo_golden), ("moves", moves_golden), ("sampler", sampler_golden),
+                     ("overlap", overlap_golden)):
         if only and name not in only:
             continue
         with open(os.path.join(OUT, name + ".json"), "w") as f:

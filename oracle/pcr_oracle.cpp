@@ -1102,3 +1102,48 @@ extern "C" int orc_random_assays(orc_session *s, unsigned *seed, unsigned n_tria
 	}
 	catch(const char *e){ s->err = e; return -1; }
 }
+
+// ------------------------------------------------------------------------------------ oligo reuse (multiplex Score term)
+namespace {
+
+// Word::max_overlap, word.h:38-91: one DP row over the subject; a cell takes its diagonal predecessor and adds
+// one where the two nibbles are EQUAL (a mismatch keeps the count): the best ungapped diagonal, as a fraction
+// of the longer word.
+float max_overlap(const W &a, const W &b)
+{
+	unsigned char dp[32];
+	memset(dp, 0, sizeof(dp));
+	unsigned char max_score = 0;
+	const int qs = a.start(), qe = a.stop(), ss = b.start(), se = b.stop();
+	for(int i = qs;i <= qe;++i){
+		unsigned char last = 0;
+		const unsigned q = a.get(i);
+		for(int j = ss;j <= se;++j){
+			const unsigned char cur = dp[j];
+			dp[j] = last;
+			if(b.get(j) == q){ ++dp[j]; if(max_score < dp[j]) max_score = dp[j]; }
+			last = cur;
+		}
+	}
+	return float(max_score)/std::max(a.size(), b.size());
+}
+
+} // namespace
+
+extern "C" float orc_word_max_overlap(const uint64_t a[2], const uint64_t b[2])
+{
+	W x, y; x.b[0] = a[0]; x.b[1] = a[1]; y.b[0] = b[0]; y.b[1] = b[1];
+	return max_overlap(x, y);
+}
+
+extern "C" float orc_oligo_overlap(const uint64_t assay[4], const uint64_t *pool, unsigned n_pool)   // pcr_assay.cpp:736-754
+{
+	W f, r; f.b[0] = assay[0]; f.b[1] = assay[1]; r.b[0] = assay[2]; r.b[1] = assay[3];
+	float best_f = 0.0f, best_r = 0.0f;
+	for(unsigned i = 0;i < n_pool;++i){
+		W pf, pr; pf.b[0] = pool[4*i]; pf.b[1] = pool[4*i + 1]; pr.b[0] = pool[4*i + 2]; pr.b[1] = pool[4*i + 3];
+		best_f = std::max(best_f, max_overlap(f, pf)); best_f = std::max(best_f, max_overlap(f, pr));
+		best_r = std::max(best_r, max_overlap(r, pf)); best_r = std::max(best_r, max_overlap(r, pr));
+	}
+	return ((best_f == 1.0f) ? 10.0f : best_f) + ((best_r == 1.0f) ? 10.0f : best_r);   // MULTIPLEX_OLIGO_REUSE_BONUS, assay.h:19
+}

@@ -52,6 +52,9 @@ void orc_word_shift_left(uint64_t w[2]);                                   // wo
 void orc_word_shift_right(uint64_t w[2]);                                  // word.cpp:224
 int orc_word_expand(const uint64_t in[2], uint64_t *out, int cap);         // word.h:525-647
 float orc_taq_mama(unsigned p1, unsigned p2, unsigned t1, unsigned t2);    // word.cpp:249-294
+float orc_word_max_overlap(const uint64_t a[2], const uint64_t b[2]);        // word.h:38-91
+// PCR::compute_oligo_overlap (pcr_assay.cpp:736-754): assay = {F[2], R[2]}, pool = n x {F[2], R[2]}
+float orc_oligo_overlap(const uint64_t assay[4], const uint64_t *pool, unsigned n_pool);
 
 // ---- Sequence::pack (sequence.cpp:92-267).  '-' in `seq` = Base::EOS.
 long orc_pack(const char *seq, unsigned index, unsigned degen_thr, float min_gc, float max_gc,

@@ -730,6 +730,25 @@ int ref_random_assays(RefSession *s, unsigned *seed, unsigned n_trials, const Re
 	catch(...){ s->last_error = "unknown"; return -2; }
 }
 
+// Word::max_overlap (word.h:38-91) and PCR::compute_oligo_overlap (pcr_assay.cpp:736-754)
+float ref_word_max_overlap(const uint64_t a[2], const uint64_t b[2])
+{
+	return word_from(a).max_overlap( word_from(b) );
+}
+
+float ref_oligo_overlap(const uint64_t assay[4], const uint64_t *pool, unsigned n_pool)
+{
+	PCR p;
+	p.oligo( FORWARD, word_from(assay) );
+	p.oligo( REVERSE, word_from(assay + 2) );
+	deque<PCR> q(n_pool);
+	for(unsigned i = 0;i < n_pool;++i){
+		q[i].oligo( FORWARD, word_from(pool + 4*i) );
+		q[i].oligo( REVERSE, word_from(pool + 4*i + 2) );
+	}
+	return p.compute_oligo_overlap(q);
+}
+
 // The SantaLucia parameter set as the reference initialises it (published values:
 // SantaLucia & Hicks, Annu. Rev. Biophys. Biomol. Struct. 33:415-440, 2004), for
 // oracle/gen_thermo_tables.py.  scalars: init_H, init_S, asymmetric_loop_dS, bulge_AT_closing_S,

@@ -90,7 +90,7 @@ ABI_SYMBOLS = [
     "pcr_host_orientation_seeds", "pcr_host_move_trials",
     "pcr_sw_align_words", "pcr_background_match", "pcr_multiplex_match",
     "pcr_thermo", "pcr_dimer", "pcr_multiplex_compatible",
-    "pcr_random_assays", "pcr_host_rand_r",
+    "pcr_random_assays", "pcr_host_rand_r", "pcr_host_max_overlap", "pcr_host_oligo_overlap",
 ]
 
 
@@ -145,6 +145,10 @@ def load_library():
     L.pcr_multiplex_compatible.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(ThermoArgs), C.c_void_p]
     L.pcr_random_assays.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(SamplerArgs),
                                     C.POINTER(ThermoArgs), C.c_void_p, C.c_void_p]
+    L.pcr_host_max_overlap.restype = C.c_float
+    L.pcr_host_max_overlap.argtypes = [C.c_void_p, C.c_void_p]
+    L.pcr_host_oligo_overlap.restype = C.c_float
+    L.pcr_host_oligo_overlap.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
     L.pcr_host_rand_r.restype = C.c_uint32
     L.pcr_host_rand_r.argtypes = [C.POINTER(C.c_uint32)]
     L.pcr_host_irregular_words.restype = C.c_int64
@@ -189,6 +193,22 @@ def host_window_valid(packed, length, pack_max_degen=256, pack_min_gc=0.0, pack_
     if L.pcr_host_window_valid(buf.ctypes.data, length, C.byref(p), out.ctypes.data) != 0:
         raise PcrError(_err(L))
     return out[:length]
+
+
+def host_max_overlap(a, b):
+    """Word::max_overlap (word.h:38-91) -> float32."""
+    L = load_library()
+    x = np.array([int(a[0]), int(a[1])], dtype=np.uint64)
+    y = np.array([int(b[0]), int(b[1])], dtype=np.uint64)
+    return np.float32(L.pcr_host_max_overlap(x.ctypes.data, y.ctypes.data))
+
+
+def host_oligo_overlap(assay, pool):
+    """PCR::compute_oligo_overlap (pcr_assay.cpp:736-754): assay (F, R) against a pool of (F, R) -> float32."""
+    L = load_library()
+    a = W.pairs_array([assay])
+    p = W.pairs_array(pool) if len(pool) else np.zeros((0, 4), np.uint64)
+    return np.float32(L.pcr_host_oligo_overlap(a.ctypes.data, p.ctypes.data if len(pool) else None, len(pool)))
 
 
 def host_rand_r(seed):

@@ -451,6 +451,38 @@ inline bool expand_oligo(const Planes &w, std::vector<std::vector<uint8_t> > &ou
 	return true;
 }
 
+// Word::max_overlap (word.h:38-91): the DP there gives a cell its diagonal predecessor's count plus one where
+// the two nibbles are equal, so the maximum is the best ungapped diagonal: for every relative shift, the
+// number of slots (inside both words' start..stop ranges) holding the same code, over the longer word's size.
+inline float max_overlap(const Planes &a, const Planes &b)
+{
+	const uint32_t oa = planes_occupied(a), ob = planes_occupied(b);
+	if(!oa || !ob) return 0.0f;                                                  // an empty word is undefined in the reference (its unsigned loop bounds wrap); defined as 0 here
+	auto range = [](uint32_t o){ const int lo = __builtin_ctz(o), hi = 31 - __builtin_clz(o); return (hi - lo == 31) ? 0xFFFFFFFFu : (((1u << (hi - lo + 1)) - 1u) << lo); };
+	const uint32_t ra = range(oa), rb = range(ob);
+	int best = 0;
+	for(int d = -31;d <= 31;++d){                                                // b slot j meets a slot j + d
+		auto sh = [d](uint32_t v){ return (d >= 0) ? (v << d) : (v >> (-d)); };
+		const uint32_t both = ra & sh(rb);
+		if(!both) continue;
+		const uint32_t diff = (a.a ^ sh(b.a)) | (a.c ^ sh(b.c)) | (a.g ^ sh(b.g)) | (a.t ^ sh(b.t));
+		best = std::max(best, __builtin_popcount(both & ~diff));
+	}
+	return float(best)/float(std::max(planes_size(a), planes_size(b)));
+}
+
+// PCR::compute_oligo_overlap (pcr_assay.cpp:736-754) with MULTIPLEX_OLIGO_REUSE_BONUS (assay.h:19)
+inline float oligo_overlap(const Planes &f, const Planes &r, const Planes *pool_fr, uint32_t n_pool)
+{
+	float best_f = 0.0f, best_r = 0.0f;
+	for(uint32_t i = 0;i < n_pool;++i){
+		const Planes &pf = pool_fr[2*i], &pr = pool_fr[2*i + 1];
+		best_f = std::max(best_f, max_overlap(f, pf)); best_f = std::max(best_f, max_overlap(f, pr));
+		best_r = std::max(best_r, max_overlap(r, pf)); best_r = std::max(best_r, max_overlap(r, pr));
+	}
+	return ((best_f == 1.0f) ? 10.0f : best_f) + ((best_r == 1.0f) ? 10.0f : best_r);
+}
+
 // glibc rand_r (stdlib/rand_r.c, glibc 2.35): the reference's only random source (sample.cpp:12,
 // pcr_assay.cpp:618-638, main.cpp:542).  Restated so that the sampler does not depend on the host libc.
 inline uint32_t rand_r_glibc(uint32_t *seed)

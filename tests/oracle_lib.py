@@ -142,6 +142,19 @@ class _Lib:
     def centered_word(self, s):
         return self.word_center(self.word(s))
 
+    def max_overlap(self, a, b):
+        fn = self._f("word_max_overlap")
+        fn.restype = C.c_float
+        return fn(_w(a), _w(b))
+
+    def oligo_overlap(self, assay, pool):
+        fn = getattr(self.lib, self.prefix + "oligo_overlap")
+        fn.restype = C.c_float
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]
+        a = pairs_array([assay])
+        p = pairs_array(pool) if len(pool) else np.zeros((1, 4), dtype=np.uint64)
+        return fn(a.ctypes.data, p.ctypes.data, len(pool))
+
     def taq_mama(self, p1, p2, t1, t2):
         return self._f("taq_mama")(p1, p2, t1, t2)
 

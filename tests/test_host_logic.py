@@ -227,3 +227,36 @@ def test_host_rand_r_is_glibc_rand_r():
                 got, s = api.host_rand_r(s)
                 assert got == v
             assert s == after
+
+
+def test_host_overlap_helpers(oracle):
+    """pcr_host_max_overlap / pcr_host_oligo_overlap (bit-plane form) against the oracle's DP restatement and the
+    reference's own values (golden)."""
+    import json
+    import os
+    import random
+    from testdata import rand_seq
+    rng = random.Random(17)
+    words = []
+    for _ in range(150):
+        w = oracle.word(rand_seq(rng, rng.randint(1, 32), p_degen=0.25))
+        for _ in range(rng.randint(0, 8)):
+            w = oracle.word_shift_right(w)
+        words.append(w)
+    words += [oracle.word("ACGTACGTACGTACGTACGTACGTACGTACGT"), oracle.word("A"), words[3]]
+    for a in words[::2]:
+        for b in words:
+            assert api.host_max_overlap(a, b) == np.float32(oracle.max_overlap(a, b)), (a, b)
+    for _ in range(150):
+        assay = (rng.choice(words), rng.choice(words))
+        pool = [(rng.choice(words), rng.choice(words)) for _ in range(rng.randint(0, 7))]
+        assert api.host_oligo_overlap(assay, pool) == np.float32(oracle.oligo_overlap(assay, pool))
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "overlap.json")) as f:
+        g = json.load(f)
+    gw = [(int(h[0], 16), int(h[1], 16)) for h in g["words"]]
+    for i, j, v in g["max_overlap"]:
+        assert api.host_max_overlap(gw[i], gw[j]) == np.float32(v)
+    for c in g["oligo_overlap"]:
+        a = c["assay"]
+        pool = [((int(p[0], 16), int(p[1], 16)), (int(p[2], 16), int(p[3], 16))) for p in c["pool"]]
+        assert api.host_oligo_overlap(((int(a[0], 16), int(a[1], 16)), (int(a[2], 16), int(a[3], 16))), pool) == np.float32(c["overlap"])

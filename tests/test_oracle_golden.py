@@ -152,3 +152,19 @@ def test_sampler(oracle, ci):
         got, s = random_assays(oracle, sess, seed, len(pairs), **c["sampler_options"])
         assert got == [((int(p[0], 16), int(p[1], 16)), (int(p[2], 16), int(p[3], 16))) for p in pairs], seed
         assert s == after, seed
+
+
+def _hw(h):
+    return (int(h[0], 16), int(h[1], 16))
+
+
+def test_overlap(oracle):
+    """Word::max_overlap / PCR::compute_oligo_overlap as the reference computed them."""
+    g = load("overlap")
+    words = [_hw(h) for h in g["words"]]
+    for i, j, v in g["max_overlap"]:
+        assert np.float32(oracle.max_overlap(words[i], words[j])) == np.float32(v), (i, j)
+    for c in g["oligo_overlap"]:
+        a = c["assay"]
+        pool = [((int(p[0], 16), int(p[1], 16)), (int(p[2], 16), int(p[3], 16))) for p in c["pool"]]
+        assert np.float32(oracle.oligo_overlap((_hw(a[:2]), _hw(a[2:])), pool)) == np.float32(c["overlap"])

@@ -501,3 +501,23 @@ def test_random_assay_errors(oracle, reference):
         s.add_target("A" * 400, 1.0, True)                             # nothing passes the Tm filter
         with pytest.raises(RuntimeError, match="Unable to generate"):
             random_assays(lib, s, 1, 1)
+
+
+def test_max_overlap_and_oligo_overlap(oracle, reference):
+    """Word::max_overlap (word.h:38-91) and PCR::compute_oligo_overlap (pcr_assay.cpp:736-754)."""
+    rng = random.Random(99)
+    words = []
+    for _ in range(120):
+        w = reference.word(rand_seq(rng, rng.randint(12, 32), p_degen=0.2))
+        for _ in range(rng.randint(0, 6)):
+            w = reference.word_shift_right(w)
+        words.append(w)
+    stem = rand_seq(rng, 32)
+    words += [reference.centered_word(stem[k:k + 20]) for k in range(10)] + [reference.centered_word(stem[:20])]
+    for a in words[::3]:
+        for b in words:
+            assert oracle.max_overlap(a, b) == reference.max_overlap(a, b)
+    for _ in range(200):
+        assay = (rng.choice(words), rng.choice(words))
+        pool = [(rng.choice(words), rng.choice(words)) for _ in range(rng.randint(0, 8))]
+        assert oracle.oligo_overlap(assay, pool) == reference.oligo_overlap(assay, pool)
