@@ -245,6 +245,23 @@ int pcr_dimer(pcr_ctx *ctx, const pcr_pair *pairs, uint32_t n, const pcr_thermo_
 int pcr_multiplex_compatible(pcr_ctx *ctx, const pcr_pair *a, const pcr_pair *b, uint32_t n,
 	const pcr_thermo_args *args, uint8_t *ok);
 
+/* ---- Multiplex background (the third coverage term of the multiplex local search) */
+
+/* The multiplex background DB and its keys (main.cpp:989-1001): every word Sequence::pack emits for the
+ * amplicon sequences of the assays accepted so far (pack_max_degen of pcr_create, no G+C filter,
+ * min_oligo_length = opt.min_oligo_length()), made unique.  The call REPLACES the key table: pass all amplicons
+ * collected so far.  Sequence format as pcr_load_sequences.  n_keys_out (optional) = keys(db).size(). */
+int pcr_multiplex_load(pcr_ctx *ctx, const uint8_t *packed4, const uint64_t *byte_offsets, const uint64_t *lengths,
+	uint32_t n, uint32_t min_oligo_length, uint64_t *n_keys_out);
+
+/* collect_multiplex_background_candidates (pcr_assay.cpp:71-102) for `base`, then, for every trial word of the
+ * oligo on `side` (0 = F, 1 = R), update_identity of that oligo's map (optimize.cpp:209-261) and
+ * compute_multiplex_background_coverage (pcr_assay.cpp:304-336): coverage[v] = number of distinct candidate
+ * keys whose identity with the forward or with the reverse oligo is >= background_threshold.  The unedited
+ * assay is the variant `base->f` (side 0). */
+int pcr_multiplex_coverage(pcr_ctx *ctx, const pcr_pair *base, int side, const pcr_word128 *variants, uint32_t n_variants,
+	float background_threshold, int use_taq_mama, float *coverage);
+
 /* ---- Random assay sampler (scope row f-2) */
 
 /* The `Options` fields PCR::random_assay reads besides the thermodynamic ones (pcramp.h:21-30). */

@@ -322,6 +322,32 @@ def overlap_golden(ref):
     return {"words": [hexw(w) for w in words], "max_overlap": pairs, "oligo_overlap": assays}
 
 
+def multiplex_golden(ref):
+    """Multiplex background coverage (pcr_assay.cpp:71-102, :304-336) over amplicon-like sequences packed as
+    main.cpp:989-1001 packs accepted amplicons: key count and the coverage of every move variant."""
+    from testdata import multiplex_case, move_variants
+    from pcramp_amd import words as W
+    cases = []
+    for taq in (0, 1):
+        rng = random.Random(7300 + taq)
+        amps, pairs = multiplex_case(rng, W, ref, n_amp=8)
+        sess = ref.session(min_primer=18)
+        for a in amps:
+            sess.add_target(a, 1.0)
+        rows = []
+        for pi, p in enumerate(pairs[:6]):
+            for side in (0, 1):
+                var = [p[side]]
+                for kind in ("inc", "dec", "trim5", "trim3", "grow5", "grow3"):
+                    var += move_variants(W, p[side], kind)
+                for thr in (0.8, 0.65):
+                    cov, nk = sess.multiplex_coverage(p, side, var, thr, taq)
+                    rows.append([pi, side, thr, [hexw(v) for v in var], [float(c) for c in cov], nk])
+        cases.append({"use_taq_mama": taq, "amplicons": amps, "min_primer": 18, "pairs": [hexw(f) + hexw(r) for f, r in pairs[:6]],
+                      "rows": rows})
+    return {"cases": cases}
+
+
 def main():
     build_reference()
     ref = Reference()
@@ -329,7 +355,7 @@ def main():
     only = set(sys.argv[1:])
     for name, fn in (("words", words_golden), ("pack", pack_golden), ("screen", screen_golden), ("sw", sw_golden),
                      ("thermo", thermo_golden), ("moves", moves_golden), ("sampler", sampler_golden),
-                     ("overlap", overlap_golden)):
+                     ("overlap", overlap_golden), ("multiplex", multiplex_golden)):
         if only and name not in only:
             continue
         with open(os.path.join(OUT, name + ".json"), "w") as f:

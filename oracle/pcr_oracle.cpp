@@ -1147,3 +1147,37 @@ extern "C" float orc_oligo_overlap(const uint64_t assay[4], const uint64_t *pool
 	}
 	return ((best_f == 1.0f) ? 10.0f : best_f) + ((best_r == 1.0f) ? 10.0f : best_r);   // MULTIPLEX_OLIGO_REUSE_BONUS, assay.h:19
 }
+
+// ------------------------------------------------------------------------------------ multiplex background coverage
+extern "C" int orc_multiplex_coverage(orc_session *s, const uint64_t base[4], int side, const uint64_t *variants, unsigned n_variants,
+	float background_threshold, int use_taq_mama, float *cov_out, unsigned *n_keys_out)
+{
+	std::vector<Entry> db;                                                        // main.cpp:989-998
+	for(size_t i = 0;i < s->seq.size();++i) pack(s->seq[i], (unsigned)i, s->opt.pack_max_degen, 0.0f, 1.0f, (unsigned)s->opt.min_primer, db);
+	std::stable_sort(db.begin(), db.end(), entry_key_less);
+	std::vector<W> keys;                                                          // keys(), pcramp.h:231-256
+	for(const Entry &e : db){ if(keys.empty() || !(keys.back() == e.w)) keys.push_back(e.w); }
+	if(n_keys_out) *n_keys_out = (unsigned)keys.size();
+	const W F = load_word(base), R = load_word(base + 2);
+	std::map<uint32_t, float> fi, ri;
+	if(!keys.empty()){                                                            // collect_multiplex_background_candidates, pcr_assay.cpp:71-102
+		std::vector<uint32_t> m;
+		match_words(m, F, keys, background_threshold);
+		for(uint32_t k : m) fi[k] = 0.0f;
+		m.clear();
+		match_words(m, R, keys, background_threshold);
+		for(uint32_t k : m) ri[k] = 0.0f;
+	}
+	update_identity(fi, F, keys, use_taq_mama != 0);                              // update_multiplex_background_candidates, assay.h:448-452
+	update_identity(ri, R, keys, use_taq_mama != 0);
+	for(unsigned v = 0;v < n_variants;++v){
+		const W w = load_word(variants + 2*v);
+		update_identity(side == 0 ? fi : ri, w, keys, use_taq_mama != 0);         // optimize_pcr.cpp:111-119
+		double ret = 0.0;                                                         // compute_multiplex_background_coverage, pcr_assay.cpp:304-336
+		std::set<uint32_t> valid;
+		for(const auto &kv : fi){ if(kv.second >= background_threshold && !valid.count(kv.first)){ valid.insert(kv.first); ret += 1.0; } }
+		for(const auto &kv : ri){ if(kv.second >= background_threshold && !valid.count(kv.first)){ valid.insert(kv.first); ret += 1.0; } }
+		cov_out[v] = (float)ret;
+	}
+	return 0;
+}

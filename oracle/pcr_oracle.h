@@ -107,6 +107,11 @@ int orc_optimization_move(orc_session *t, orc_session *b, const uint64_t pair[4]
 int orc_optimize(orc_session *t, orc_session *b, uint64_t pair_inout[4], const int *moves, int n_moves,
 	const orc_move_options *mo, float out_score[3], int *iterations_out);
 
+// Multiplex background coverage (pcr_assay.cpp:71-102, :304-336) with the session's sequences as the accepted
+// amplicons: DB = pack of every sequence (session pack_max_degen, no G+C filter, min_primer; main.cpp:989-1001),
+// candidates of `base`, then per trial word of the oligo on `side` update_identity + the distinct-key count.
+int orc_multiplex_coverage(orc_session *s, const uint64_t base[4], int side, const uint64_t *variants, unsigned n_variants,
+	float background_threshold, int use_taq_mama, float *cov_out, unsigned *n_keys_out);
 float orc_weighted_coverage(orc_session *s, const unsigned char *bits);
 
 // ---- Smith-Waterman (SO::SeqOverlap, SmithWaterman + nucleic-acid mode; seq_overlap.cpp:347-609)

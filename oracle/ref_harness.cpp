@@ -749,6 +749,41 @@ float ref_oligo_overlap(const uint64_t assay[4], const uint64_t *pool, unsigned 
 	return p.compute_oligo_overlap(q);
 }
 
+// The multiplex background coverage as optimize() / the moves evaluate it (optimize.cpp:82-92,
+// optimize_pcr.cpp:111-127): DB = pack of the session's sequences the way main.cpp:989-1001 packs accepted
+// amplicons, candidates of the base assay, identity map of the edited oligo recomputed per trial word.
+int ref_multiplex_coverage(RefSession *s, const uint64_t base[4], int side, const uint64_t *variants, unsigned n_variants,
+	float background_threshold, int use_taq_mama, float *cov_out, unsigned *n_keys_out)
+{
+	try{
+		MULTIMAP<Word, WordMatch> db;
+		deque<Sequence> seqs;
+		for(deque<Sequence>::const_iterator i = s->target_seq.begin();i != s->target_seq.end();++i){
+			i->pack(db, seqs.size(), s->opt.pack_max_degen, 0.0, 1.0, s->opt.min_oligo_length());
+			seqs.push_back(*i);
+		}
+		db.sort();
+		const vector<Word> mkeys = keys(db);
+		if(n_keys_out) *n_keys_out = (unsigned)mkeys.size();
+		Options opt = s->opt;
+		opt.background_threshold = background_threshold;
+		opt.use_taq_mama = (use_taq_mama != 0);
+		PCR p;
+		p.oligo( FORWARD, word_from(base) );
+		p.oligo( REVERSE, word_from(base + 2) );
+		p.collect_multiplex_background_candidates(mkeys, db, seqs, opt);
+		p.update_multiplex_background_candidates(mkeys, opt.use_taq_mama);
+		for(unsigned v = 0;v < n_variants;++v){
+			const Word trial = word_from(variants + 2*v);
+			update_identity( (side == 0) ? p.multiplex_background_f_identity : p.multiplex_background_r_identity, trial, mkeys, opt.use_taq_mama );
+			cov_out[v] = p.compute_multiplex_background_coverage(opt.background_threshold);
+		}
+		return 0;
+	}
+	catch(const char *e){ s->last_error = e; return -1; }
+	catch(...){ s->last_error = "unknown"; return -2; }
+}
+
 // The SantaLucia parameter set as the reference initialises it (published values:
 // SantaLucia & Hicks, Annu. Rev. Biophys. Biomol. Struct. 33:415-440, 2004), for
 // oracle/gen_thermo_tables.py.  scalars: init_H, init_S, asymmetric_loop_dS, bulge_AT_closing_S,

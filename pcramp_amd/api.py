@@ -91,6 +91,7 @@ ABI_SYMBOLS = [
     "pcr_sw_align_words", "pcr_background_match", "pcr_multiplex_match",
     "pcr_thermo", "pcr_dimer", "pcr_multiplex_compatible",
     "pcr_random_assays", "pcr_host_rand_r", "pcr_host_max_overlap", "pcr_host_oligo_overlap",
+    "pcr_multiplex_load", "pcr_multiplex_coverage",
 ]
 
 
@@ -145,6 +146,8 @@ def load_library():
     L.pcr_multiplex_compatible.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(ThermoArgs), C.c_void_p]
     L.pcr_random_assays.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(SamplerArgs),
                                     C.POINTER(ThermoArgs), C.c_void_p, C.c_void_p]
+    L.pcr_multiplex_load.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
+    L.pcr_multiplex_coverage.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_float, C.c_int, C.c_void_p]
     L.pcr_host_max_overlap.restype = C.c_float
     L.pcr_host_max_overlap.argtypes = [C.c_void_p, C.c_void_p]
     L.pcr_host_oligo_overlap.restype = C.c_float
@@ -475,6 +478,30 @@ class Screener:
             return np.frombuffer(out, dtype=np.uint32).reshape(-1, 8)[:len(oligos), 0] != 0
         return [dict(valid=bool(r.valid), n=r.n_expansions, tm=np.float32(r.tm), dH=np.float32(r.dH), dS=np.float32(r.dS),
                      hairpin_tm=np.float32(r.hairpin_tm), homodimer_tm=np.float32(r.homodimer_tm)) for r in out[:len(oligos)]]
+
+    def multiplex_load(self, seqs, min_oligo_length=18):
+        """The multiplex background keys (main.cpp:989-1001) from amplicon texts -> number of unique keys."""
+        packs = [W.pack_codes(W.codes_from_text(s)) for s in seqs]
+        off = np.zeros(max(len(seqs), 1), dtype=np.uint64)
+        tot = 0
+        for i, p in enumerate(packs):
+            off[i] = tot
+            tot += len(p)
+        flat = np.concatenate(packs) if packs else np.zeros(1, np.uint8)
+        ln = np.array([len(s) for s in seqs] or [0], dtype=np.uint64)
+        nk = C.c_uint64(0)
+        self._check(self.L.pcr_multiplex_load(self.h, flat.ctypes.data, off.ctypes.data, ln.ctypes.data, len(seqs),
+                                              int(min_oligo_length), C.byref(nk)))
+        return int(nk.value)
+
+    def multiplex_coverage(self, base_pair, side, variants, background_threshold=0.8, use_taq_mama=False):
+        """compute_multiplex_background_coverage for every trial word of one oligo -> float32[n_variants]."""
+        a = W.pairs_array([base_pair])
+        v = np.array([[int(w[0]), int(w[1])] for w in variants], dtype=np.uint64).reshape(-1, 2)
+        cov = np.zeros(max(v.shape[0], 1), np.float32)
+        self._check(self.L.pcr_multiplex_coverage(self.h, a.ctypes.data, int(side), v.ctypes.data, v.shape[0],
+                                                  float(background_threshold), int(use_taq_mama), cov.ctypes.data))
+        return cov[:v.shape[0]]
 
     def random_assays(self, seed, n_trials, primer_min=18, primer_max=25, amp_min=80, amp_max=200, max_degen=1.0, salt=0.05,
                       primer_strand=9e-7, tm_min=50.0, tm_max=70.0, max_hairpin=40.0, max_dimer=40.0, which=TARGET):

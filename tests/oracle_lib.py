@@ -463,6 +463,20 @@ class Session:
             raise RuntimeError(self.f("session_error")(self.h))
         return cov[:len(variants)]
 
+    def multiplex_coverage(self, base_pair, side, variants, background_threshold=0.8, use_taq_mama=0):
+        """The session's sequences as accepted amplicons -> (float32[n_variants], number of keys)."""
+        a = pairs_array([base_pair])
+        v = np.array([[int(w[0]), int(w[1])] for w in variants], dtype=np.uint64).reshape(-1, 2)
+        cov = np.zeros(max(len(variants), 1), dtype=np.float32)
+        nk = C.c_uint(0)
+        fn = getattr(self.L.lib, self.L.prefix + "multiplex_coverage")
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_uint, C.c_float, C.c_int, C.c_void_p, C.POINTER(C.c_uint)]
+        rc = fn(self.h, a.ctypes.data, int(side), v.ctypes.data, len(variants), background_threshold, int(use_taq_mama),
+                cov.ctypes.data, C.byref(nk))
+        if rc != 0:
+            raise RuntimeError(self.f("session_error")(self.h))
+        return cov[:len(variants)], nk.value
+
     def background_match(self, pair, bg_threshold=0.8, bg_multiplier=0.9, amp_min=0, amp_max=2000, use_taq_mama=0,
                          emulate_index_bug=0):
         """-> (bits uint8[n], n_amplicons or None).  Reference: returns None bits when the reference's

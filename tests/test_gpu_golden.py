@@ -134,3 +134,22 @@ def test_sampler_golden(ci):
             assert s == after, seed
     finally:
         d.close()
+
+
+@pytest.mark.parametrize("ci", range(2))
+def test_multiplex_golden(ci):
+    """pcr_multiplex_load + pcr_multiplex_coverage against tests/golden/multiplex.json (the reference's
+    compute_multiplex_background_coverage over a DB packed like main.cpp:989-1001)."""
+    with open(os.path.join(G, "multiplex.json")) as f:
+        c = json.load(f)["cases"][ci]
+    hw = lambda h: (int(h[0], 16), int(h[1], 16))
+    d = api.Screener(0)
+    try:
+        nk = d.multiplex_load(c["amplicons"], c["min_primer"])
+        pairs = [(hw(p[:2]), hw(p[2:])) for p in c["pairs"]]
+        for pi, side, thr, var, cov, want_keys in c["rows"]:
+            assert nk == want_keys
+            got = d.multiplex_coverage(pairs[pi], side, [hw(v) for v in var], thr, bool(c["use_taq_mama"]))
+            assert np.array_equal(got, np.array(cov, np.float32)), (pi, side, thr)
+    finally:
+        d.close()

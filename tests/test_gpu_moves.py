@@ -235,3 +235,36 @@ def test_optimize_loop_matches_oracle(oracle, case):
         assert changed > 0
     finally:
         d.close()
+
+
+@pytest.mark.parametrize("taq", [0, 1])
+def test_multiplex_coverage_matches_oracle(oracle, taq):
+    """The multiplex background term: unique keys of the accepted amplicons (host window model) and the
+    distinct-key count per trial word, against the oracle (itself == the compiled reference)."""
+    from testdata import multiplex_case
+    rng = random.Random(3300 + taq)
+    amps, pairs = multiplex_case(rng, W, oracle, n_amp=30)
+    so = oracle.session(min_primer=18)
+    for a in amps:
+        so.add_target(a, 1.0)
+    d = api.Screener(0)
+    try:
+        assert d.multiplex_coverage(pairs[0], 0, [pairs[0][0]]).tolist() == [0.0]   # no keys loaded yet
+        nk = d.multiplex_load(amps, 18)
+        nonzero = 0
+        for p in pairs:
+            for side in (0, 1):
+                var = [p[side]]
+                for kind in ("inc", "dec", "trim5", "trim3", "grow5", "grow3"):
+                    var += move_variants(W, p[side], kind)
+                for thr in (0.8, 0.65, 1.0):
+                    co, ko = so.multiplex_coverage(p, side, var, thr, taq)
+                    assert ko == nk
+                    cd = d.multiplex_coverage(p, side, var, thr, bool(taq))
+                    assert np.array_equal(cd, co), (p, side, thr)
+                    nonzero += int(np.count_nonzero(co))
+        assert nonzero > 200
+        assert d.multiplex_load([], 18) == 0                           # an empty pool: coverage 0 (pcr_assay.cpp:306)
+        assert d.multiplex_coverage(pairs[0], 0, [pairs[0][0]]).tolist() == [0.0]
+    finally:
+        d.close()

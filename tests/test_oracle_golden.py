@@ -168,3 +168,16 @@ def test_overlap(oracle):
         a = c["assay"]
         pool = [((int(p[0], 16), int(p[1], 16)), (int(p[2], 16), int(p[3], 16))) for p in c["pool"]]
         assert np.float32(oracle.oligo_overlap((_hw(a[:2]), _hw(a[2:])), pool)) == np.float32(c["overlap"])
+
+
+@pytest.mark.parametrize("ci", range(2))
+def test_multiplex_coverage(oracle, ci):
+    c = load("multiplex")["cases"][ci]
+    sess = oracle.session(min_primer=c["min_primer"])
+    for a in c["amplicons"]:
+        sess.add_target(a, 1.0)
+    pairs = [(_hw(p[:2]), _hw(p[2:])) for p in c["pairs"]]
+    for pi, side, thr, var, cov, nk in c["rows"]:
+        got, k = sess.multiplex_coverage(pairs[pi], side, [_hw(v) for v in var], thr, c["use_taq_mama"])
+        assert k == nk
+        assert np.array_equal(got, np.array(cov, np.float32)), (pi, side, thr)

@@ -521,3 +521,31 @@ def test_max_overlap_and_oligo_overlap(oracle, reference):
         assay = (rng.choice(words), rng.choice(words))
         pool = [(rng.choice(words), rng.choice(words)) for _ in range(rng.randint(0, 8))]
         assert oracle.oligo_overlap(assay, pool) == reference.oligo_overlap(assay, pool)
+
+
+@pytest.mark.parametrize("taq", [0, 1])
+def test_multiplex_background_coverage(oracle, reference, taq):
+    """collect_multiplex_background_candidates + update_identity + compute_multiplex_background_coverage (the
+    reference's own, over a DB packed like main.cpp:989-1001) against the oracle: key count and the coverage of
+    every move variant of both oligos."""
+    from testdata import multiplex_case, move_variants
+    from pcramp_amd import words as W
+    rng = random.Random(640 + taq)
+    amps, pairs = multiplex_case(rng, W, reference)
+    so, sr = oracle.session(min_primer=18), reference.session(min_primer=18)
+    for a in amps:
+        so.add_target(a, 1.0)
+        sr.add_target(a, 1.0)
+    nonzero = 0
+    for p in pairs:
+        for side in (0, 1):
+            var = [p[side]]
+            for kind in ("inc", "dec", "trim5", "trim3", "grow5", "grow3"):
+                var += move_variants(W, p[side], kind)
+            for thr in (0.8, 0.65):
+                co, ko = so.multiplex_coverage(p, side, var, thr, taq)
+                cr, kr = sr.multiplex_coverage(p, side, var, thr, taq)
+                assert ko == kr and ko > 0
+                assert np.array_equal(co, cr), (p, side, thr)
+                nonzero += int(np.count_nonzero(co))
+    assert nonzero > 100

@@ -94,3 +94,31 @@ def move_variants(W, word, kind, rng=None, context=None):
         for b in (1, 2, 4, 8):
             t = list(slots); t[last + 1] = b; out.append(W.word_from_slots(t))
     return out
+
+
+def multiplex_case(rng, words_mod, lib, n_amp=12):
+    """Amplicon-like sequences (accepted assays' amplicons) and assays whose primers overlap them: primers cut
+    from the amplicons (either strand) with a few wrong bases, so that keys are matched at ~0.8 by one or both
+    oligos.  -> (amplicons, [(F, R)] as words)."""
+    amps = []
+    for i in range(n_amp):
+        a = rand_seq(rng, rng.randint(45, 260))
+        if i % 4 == 1:
+            k = rng.randrange(5, len(a) - 5)
+            a = a[:k] + rng.choice("RYKMSWN") + a[k + 1:]
+        if i % 5 == 3:
+            k = rng.randrange(20, len(a) - 20)
+            a = a[:k] + "-" + a[k + 1:]
+        amps.append(a)
+    amps.append(amps[0][10:])                                          # shares most of its words with another amplicon
+    pairs = []
+    for _ in range(10):
+        def primer():
+            a = rng.choice(amps).replace("-", "A")
+            n = rng.randint(18, 25)
+            k = rng.randrange(0, len(a) - n)
+            p = mutate(rng, a[k:k + n], rng.choice((0.0, 0.05, 0.12)))
+            return revcomp(p) if rng.random() < 0.5 else p
+        f, r = primer(), primer() if rng.random() < 0.7 else rand_seq(rng, 20)
+        pairs.append((lib.centered_word(f), lib.centered_word(r)))
+    return amps, pairs
