@@ -295,6 +295,10 @@ int pcr_random_assays(pcr_ctx *ctx, pcr_set which, uint32_t *seed, uint32_t n_tr
  * fraction of the longer one -- the oligo-reuse term of the multiplex Score (pcramp.h:158-208).  Host arithmetic. */
 float pcr_host_max_overlap(const pcr_word128 *a, const pcr_word128 *b);
 
+/* out[i] = max over both oligos of every pooled assay of Word::max_overlap(words[i], .) -- the inner loops of the
+ * moves' oligo-reuse term (optimize_pcr.cpp:27-53, :129-139) for a batch of trial words; 0 for an empty pool. */
+int pcr_host_pool_overlaps(const pcr_word128 *words, uint32_t n, const pcr_pair *pool, uint32_t n_pool, float *out);
+
 /* PCR::compute_oligo_overlap (pcr_assay.cpp:736-754): both oligos of `assay` against both oligos of every pooled
  * assay, with MULTIPLEX_OLIGO_REUSE_BONUS (assay.h:19) for an identical oligo.  Host arithmetic. */
 float pcr_host_oligo_overlap(const pcr_pair *assay, const pcr_pair *pool, uint32_t n_pool);

@@ -348,6 +348,42 @@ def multiplex_golden(ref):
     return {"cases": cases}
 
 
+def multiplex_optimize_golden(ref):
+    """optimize() with opt.use_multiplex run by the reference: final assay and Score for candidate assays against
+    targets + backgrounds + the amplicons / pool of the assays designed so far."""
+    from oracle_lib import optimize_multiplex, DEFAULT_MOVE_OPTIONS
+    from testdata import multiplex_design_case
+    cases = []
+    for ci, case in enumerate([dict(), dict(degen=8), dict(degen=16, target_threshold=0.9, use_taq_mama=1)]):
+        case = dict(case)
+        sess = {k: case.pop(k) for k in ("target_threshold", "use_taq_mama") if k in case}
+        rng = random.Random(8800 + ci)
+        seqs, bgs, amps, pool, cands = multiplex_design_case(rng, ref)
+        weights = [1.0 + 0.25 * (i % 3) for i in range(len(seqs))]
+        sopt = dict(sess, optimize_5=1, optimize_3=1)
+        ts, bs, ams = ref.session(**sopt), ref.session(**sopt), ref.session(**sess)
+        for q, wt in zip(seqs, weights):
+            ts.add_target(q, wt)
+        for q in bgs:
+            bs.add_target(q, 1.0)
+        for q in amps:
+            ams.add_target(q, 1.0)
+        allp = cands + pool
+        ts.select(allp)
+        bs.select(allp, threshold=0.8 * 0.9, min_len_override=16)
+        out = []
+        for pi, p in enumerate(cands):
+            for use_pool in (1, 0):
+                bp, sc = optimize_multiplex(ref, ts, bs, ams, pool if use_pool else [], p, **case)
+                out.append([pi, use_pool, hexw(bp[0]) + hexw(bp[1]), list(sc)])
+        mo = dict(DEFAULT_MOVE_OPTIONS); mo.update(case)
+        cases.append({"options": ts.opts, "move_options": mo, "seqs": seqs, "weights": weights, "backgrounds": bgs,
+                      "amplicons": amps, "bg_select_threshold": 0.8 * 0.9, "bg_min_len": 16,
+                      "pool": [hexw(a) + hexw(b) for a, b in pool], "candidates": [hexw(a) + hexw(b) for a, b in cands],
+                      "optimize": out})
+    return {"cases": cases}
+
+
 def main():
     build_reference()
     ref = Reference()
@@ -355,7 +391,8 @@ def main():
     only = set(sys.argv[1:])
     for name, fn in (("words", words_golden), ("pack", pack_golden), ("screen", screen_golden), ("sw", sw_golden),
                      ("thermo", thermo_golden), ("moves", moves_golden), ("sampler", sampler_golden),
-                     ("overlap", overlap_golden), ("multiplex", multiplex_golden)):
+                     ("overlap", overlap_golden), ("multiplex", multiplex_golden),
+                     ("multiplex_optimize", multiplex_optimize_golden)):
         if only and name not in only:
             continue
         with open(os.path.join(OUT, name + ".json"), "w") as f:

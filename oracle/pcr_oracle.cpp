@@ -691,11 +691,36 @@ namespace {
 // Candidates, identity tables and score of the base assay (optimize.cpp:61-79)
 struct MoveState {
 	std::vector<Amplicon> tamp, bamp;
-	std::map<uint32_t, float> tfi, tri, bfi, bri;
+	std::map<uint32_t, float> tfi, tri, bfi, bri, mfi, mri;
 	ScoreO base;
 };
 
-void move_state(MoveState &m, orc_session *t, orc_session *b, const W &F, const W &R, const orc_move_options *mo)
+float max_overlap(const W &a, const W &b);                                        // defined below (oligo reuse)
+
+// use_multiplex: the keys of the multiplex background DB (main.cpp:989-1001) and the assays designed so far
+struct Mx { std::vector<W> keys; std::vector<W> pool; /* F0, R0, F1, R1, ... */ };
+
+const float REUSE_BONUS = 10.0f;                                                   // MULTIPLEX_OLIGO_REUSE_BONUS, assay.h:19
+
+// compute_multiplex_background_coverage, pcr_assay.cpp:304-336
+float multiplex_coverage_of(const std::map<uint32_t, float> &fi, const std::map<uint32_t, float> &ri, float thr)
+{
+	if(fi.empty() && ri.empty()) return 0;
+	double ret = 0.0;
+	std::set<uint32_t> valid;
+	for(const auto &kv : fi){ if(kv.second >= thr && !valid.count(kv.first)){ valid.insert(kv.first); ret += 1.0; } }
+	for(const auto &kv : ri){ if(kv.second >= thr && !valid.count(kv.first)){ valid.insert(kv.first); ret += 1.0; } }
+	return (float)ret;
+}
+
+float pool_overlap(const W &w, const std::vector<W> &pool, float start)
+{
+	float r = start;
+	for(const W &p : pool) r = std::max(r, max_overlap(w, p));                    // F then R of every pooled assay
+	return r;
+}
+
+void move_state(MoveState &m, orc_session *t, orc_session *b, const W &F, const W &R, const orc_move_options *mo, const Mx *mx = nullptr)
 {
 	const bool taq = t->opt.use_taq_mama != 0;
 	collect_candidates(m.tamp, m.tfi, m.tri, F, R, *t, t->opt.target_threshold*t->opt.search_multiplier, t->opt.amp_min, t->opt.amp_max);
@@ -707,11 +732,26 @@ void move_state(MoveState &m, orc_session *t, orc_session *b, const W &F, const 
 	m.base.tc = coverage_of(m.tamp, m.tfi, m.tri, t->opt.target_threshold);
 	m.base.bc = coverage_of(m.bamp, m.bfi, m.bri, mo->bg_threshold);
 	m.base.ov = 0.0f;
+	m.mfi.clear(); m.mri.clear();
+	if(mx){                                                                           // optimize.cpp:79-97
+		if(!mx->keys.empty()){                                                        // collect_multiplex_background_candidates, pcr_assay.cpp:71-102
+			std::vector<uint32_t> k;
+			match_words(k, F, mx->keys, mo->bg_threshold);
+			for(uint32_t i : k) m.mfi[i] = 0.0f;
+			k.clear();
+			match_words(k, R, mx->keys, mo->bg_threshold);
+			for(uint32_t i : k) m.mri[i] = 0.0f;
+		}
+		update_identity(m.mfi, F, mx->keys, taq); update_identity(m.mri, R, mx->keys, taq);
+		m.base.bc += multiplex_coverage_of(m.mfi, m.mri, mo->bg_threshold);
+		const float bf = pool_overlap(F, mx->pool, 0.0f), br = pool_overlap(R, mx->pool, 0.0f);   // compute_oligo_overlap, pcr_assay.cpp:736-754
+		m.base.ov = ((bf == 1.0f) ? REUSE_BONUS : bf) + ((br == 1.0f) ? REUSE_BONUS : br);
+	}
 }
 
 // One move function of optimize_pcr.cpp for oligo `side` of (F, R); `thr` = m_score_threshold
 void move_eval(MoveState &m, orc_session *t, orc_session *b, const W &F, const W &R, int move, int side,
-	const orc_move_options *mo, const ScoreO &thr, W &best_w, ScoreO &best)
+	const orc_move_options *mo, const ScoreO &thr, W &best_w, ScoreO &best, const Mx *mx = nullptr)
 {
 	const bool taq = t->opt.use_taq_mama != 0;
 	const W cur = side == 0 ? F : R;
@@ -753,6 +793,13 @@ void move_eval(MoveState &m, orc_session *t, orc_session *b, const W &F, const W
 		default: throw "unknown move";
 	}
 	best = ScoreO(); best_w.b[0] = best_w.b[1] = 0;
+	// multiplex: the reuse term of the oligo that is NOT edited (e.g. optimize_pcr.cpp:27-53)
+	float partial = 0.0f;
+	if(mx){
+		partial = pool_overlap(side == 0 ? R : F, mx->pool, 0.0f);
+		if(partial == 1.0f) partial = REUSE_BONUS;
+	}
+	float carried_ov = 0.0f;   // increase_degeneracy never resets trial_score.oligo_overlap between trials (:133-145); the other moves do
 	for(const W &w : trials){
 		const int ok = orc_is_valid(w.b, mo->salt, mo->primer_strand, mo->tm_min, mo->tm_max, mo->max_hairpin, 0.0f, 0);
 		if(ok < 0) throw "is_valid failed";
@@ -761,11 +808,20 @@ void move_eval(MoveState &m, orc_session *t, orc_session *b, const W &F, const W
 		update_identity(side == 0 ? m.tfi : m.tri, w, t->keys, taq);
 		tr.tc = coverage_of(m.tamp, m.tfi, m.tri, t->opt.target_threshold);
 		const float bound = tr.tc + thr.bc - thr.tc;                                 // :95-97
-		if(bound <= 0.0f) continue;                                                   // :102-109 (non-multiplex)
+		if(mx ? (bound < 0.0f) : (bound <= 0.0f)) continue;                           // :101-109
 		if(b) update_identity(side == 0 ? m.bfi : m.bri, w, b->keys, taq);
 		tr.bc = coverage_of(m.bamp, m.bfi, m.bri, mo->bg_threshold);
+		if(mx){                                                                       // :111-145
+			update_identity(side == 0 ? m.mfi : m.mri, w, mx->keys, taq);
+			tr.bc += multiplex_coverage_of(m.mfi, m.mri, mo->bg_threshold);
+			float ov = pool_overlap(w, mx->pool, (move == 0) ? carried_ov : 0.0f);
+			ov = ((ov == 1.0f) ? REUSE_BONUS : ov) + partial;
+			tr.ov = ov;
+			carried_ov = ov;
+		}
 		if(tr.gt(best)){ best = tr; best_w = w; }
 	}
+	if(mx) update_identity(side == 0 ? m.mfi : m.mri, cur, mx->keys, taq);
 	// the move functions restore the identity tables of the unmodified oligo before returning
 	update_identity(side == 0 ? m.tfi : m.tri, cur, t->keys, taq);
 	if(b) update_identity(side == 0 ? m.bfi : m.bri, cur, b->keys, taq);
@@ -791,7 +847,7 @@ int orc_optimization_move(orc_session *t, orc_session *b, const uint64_t pair[4]
 
 // optimize() (optimize.cpp:14-207), non-multiplex: greedy local search over `moves` for both oligos.
 // pair_inout receives the best assay; returns its score.
-int orc_optimize(orc_session *t, orc_session *b, uint64_t pair_inout[4], const int *moves, int n_moves,
+static int optimize_impl(orc_session *t, orc_session *b, const Mx *mx, uint64_t pair_inout[4], const int *moves, int n_moves,
 	const orc_move_options *mo, float out_score[3], int *iterations_out)
 {
 	try{
@@ -805,7 +861,7 @@ int orc_optimize(orc_session *t, orc_session *b, uint64_t pair_inout[4], const i
 			bool improved = false;
 			++iteration;
 			MoveState m;
-			move_state(m, t, b, aF, aR, mo);                                          // :61-79
+			move_state(m, t, b, aF, aR, mo, mx);                                      // :61-97
 			approx_score = m.base;
 			if(approx_score.lt(best_score)) break;                                    // :99-105
 			best_score = approx_score; bestF = aF; bestR = aR;
@@ -815,7 +871,7 @@ int orc_optimize(orc_session *t, orc_session *b, uint64_t pair_inout[4], const i
 			for(int side = 0;side < 2;++side){                                        // :120-141
 				for(int k = 0;k < n_moves;++k){
 					W w; ScoreO sc;
-					move_eval(m, t, b, aF, aR, moves[k], side, mo, local_score, w, sc);
+					move_eval(m, t, b, aF, aR, moves[k], side, mo, local_score, w, sc, mx);
 					if(sc.gt(local_score) || (sc.eq(local_score) && w.degeneracy() < local_seq.degeneracy())){
 						local_score = sc; local_seq = w; local_oligo = side; improved = true;
 					}
@@ -834,6 +890,27 @@ int orc_optimize(orc_session *t, orc_session *b, uint64_t pair_inout[4], const i
 		return 0;
 	}
 	catch(const char *e){ t->err = e; return -1; }
+}
+
+int orc_optimize(orc_session *t, orc_session *b, uint64_t pair_inout[4], const int *moves, int n_moves,
+	const orc_move_options *mo, float out_score[3], int *iterations_out)
+{
+	return optimize_impl(t, b, nullptr, pair_inout, moves, n_moves, mo, out_score, iterations_out);
+}
+
+// optimize() with opt.use_multiplex: `amplicons` = the accepted assays' amplicons (their pack is the multiplex
+// background DB, main.cpp:989-1001), pool = n_pool x {F[2], R[2]} = the assays designed so far.
+int orc_optimize_multiplex(orc_session *t, orc_session *b, orc_session *amplicons, const uint64_t *pool, unsigned n_pool,
+	uint64_t pair_inout[4], const int *moves, int n_moves, const orc_move_options *mo, float out_score[3])
+{
+	Mx mx;
+	std::vector<Entry> db;
+	for(size_t i = 0;i < amplicons->seq.size();++i)
+		pack(amplicons->seq[i], (unsigned)i, amplicons->opt.pack_max_degen, 0.0f, 1.0f, (unsigned)amplicons->opt.min_primer, db);
+	std::stable_sort(db.begin(), db.end(), entry_key_less);
+	for(const Entry &e : db){ if(mx.keys.empty() || !(mx.keys.back() == e.w)) mx.keys.push_back(e.w); }
+	for(unsigned i = 0;i < n_pool;++i){ mx.pool.push_back(load_word(pool + 4*i)); mx.pool.push_back(load_word(pool + 4*i + 2)); }
+	return optimize_impl(t, b, &mx, pair_inout, moves, n_moves, mo, out_score, nullptr);
 }
 
 float orc_weighted_coverage(orc_session *s, const unsigned char *bits)            // main.cpp:1402-1418

@@ -462,6 +462,58 @@ int ref_optimize(RefSession *t, RefSession *b, uint64_t pair_inout[4], const int
 	catch(...){ t->last_error = "unknown"; return -2; }
 }
 
+// optimize() with opt.use_multiplex: multiplex background DB = pack of the `amplicons` session's sequences
+// (main.cpp:989-1001), pool = the assays designed so far.
+int ref_optimize_multiplex(RefSession *t, RefSession *b, RefSession *amplicons, const uint64_t *pool_words, unsigned n_pool,
+	uint64_t pair_inout[4], const int *moves, int n_moves, const RefMoveOptions *mo, float out_score[3])
+{
+	try{
+		Options opt = t->opt;
+		opt.degen = mo->degen;
+		opt.primer_range = make_pair(mo->primer_min, mo->primer_max);
+		opt.salt = mo->salt; opt.primer_strand = mo->primer_strand;
+		opt.primer_tm_range = make_pair(mo->tm_min, mo->tm_max);
+		opt.max_hairpin = mo->max_hairpin;
+		opt.background_threshold = mo->bg_threshold;
+		opt.background_search_multiplier = mo->bg_multiplier;
+		opt.background_amplicon_range = make_pair(mo->bg_amp_min, mo->bg_amp_max);
+		opt.use_multiplex = true;
+		opt.output_filter = Options::SILENT;
+		const vector<Word> no_keys;
+		const MULTIMAP<Word, WordMatch> no_db;
+		const deque<Sequence> no_seq;
+		MULTIMAP<Word, WordMatch> mdb;
+		deque<Sequence> mseq;
+		for(deque<Sequence>::const_iterator i = amplicons->target_seq.begin();i != amplicons->target_seq.end();++i){
+			i->pack(mdb, mseq.size(), amplicons->opt.pack_max_degen, 0.0, 1.0, amplicons->opt.min_oligo_length());
+			mseq.push_back(*i);
+		}
+		mdb.sort();
+		const vector<Word> mkeys = keys(mdb);
+		const Move mv[6] = { IncreaseDegeneracy, DecreaseDegeneracy, Trim5, Trim3, Grow5, Grow3 };
+		vector<Move> ml;
+		for(int i = 0;i < n_moves;++i){ if(moves[i] < 0 || moves[i] > 5) throw "unknown move"; ml.push_back(mv[moves[i]]); }
+		PCR p;
+		p.oligo( FORWARD, word_from(pair_inout) );
+		p.oligo( REVERSE, word_from(pair_inout + 2) );
+		deque<PCR> pool(n_pool);
+		for(unsigned i = 0;i < n_pool;++i){
+			pool[i].oligo( FORWARD, word_from(pool_words + 4*i) );
+			pool[i].oligo( REVERSE, word_from(pool_words + 4*i + 2) );
+		}
+		std::ostringstream sink;
+		const Score sc = optimize(p, ml, t->target_keys, t->target_db, t->target_seq,
+			b ? b->target_keys : no_keys, b ? b->target_db : no_db, b ? b->target_seq : no_seq,
+			mkeys, mdb, mseq, pool, opt, sink);
+		words_of(p.oligo(FORWARD), pair_inout);
+		words_of(p.oligo(REVERSE), pair_inout + 2);
+		out_score[0] = sc.target_coverage; out_score[1] = sc.background_coverage; out_score[2] = sc.oligo_overlap;
+		return 0;
+	}
+	catch(const char *e){ t->last_error = e; return -1; }
+	catch(...){ t->last_error = "unknown"; return -2; }
+}
+
 // ---------------------------------------------------------------- Smith-Waterman (seq_overlap)
 // One 8-lane call exactly as background_match.cpp drives it: queries/targets are arrays of
 // SO_LEN 64-bit-pair Words (slot i of each).  Outputs per lane: score, query range, target

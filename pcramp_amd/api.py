@@ -90,7 +90,7 @@ ABI_SYMBOLS = [
     "pcr_host_orientation_seeds", "pcr_host_move_trials",
     "pcr_sw_align_words", "pcr_background_match", "pcr_multiplex_match",
     "pcr_thermo", "pcr_dimer", "pcr_multiplex_compatible",
-    "pcr_random_assays", "pcr_host_rand_r", "pcr_host_max_overlap", "pcr_host_oligo_overlap",
+    "pcr_random_assays", "pcr_host_rand_r", "pcr_host_max_overlap", "pcr_host_oligo_overlap", "pcr_host_pool_overlaps",
     "pcr_multiplex_load", "pcr_multiplex_coverage",
 ]
 
@@ -148,6 +148,7 @@ def load_library():
                                     C.POINTER(ThermoArgs), C.c_void_p, C.c_void_p]
     L.pcr_multiplex_load.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
     L.pcr_multiplex_coverage.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_float, C.c_int, C.c_void_p]
+    L.pcr_host_pool_overlaps.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
     L.pcr_host_max_overlap.restype = C.c_float
     L.pcr_host_max_overlap.argtypes = [C.c_void_p, C.c_void_p]
     L.pcr_host_oligo_overlap.restype = C.c_float
@@ -204,6 +205,17 @@ def host_max_overlap(a, b):
     x = np.array([int(a[0]), int(a[1])], dtype=np.uint64)
     y = np.array([int(b[0]), int(b[1])], dtype=np.uint64)
     return np.float32(L.pcr_host_max_overlap(x.ctypes.data, y.ctypes.data))
+
+
+def host_pool_overlaps(words, pool):
+    """Largest Word::max_overlap of every word with any oligo of the pooled assays -> float32[n]."""
+    L = load_library()
+    a = np.array([[int(w[0]), int(w[1])] for w in words], dtype=np.uint64).reshape(-1, 2)
+    out = np.zeros(max(a.shape[0], 1), np.float32)
+    p = W.pairs_array(pool) if len(pool) else np.zeros((0, 4), np.uint64)
+    if L.pcr_host_pool_overlaps(a.ctypes.data, a.shape[0], p.ctypes.data if len(pool) else None, len(pool), out.ctypes.data) != 0:
+        raise PcrError(_err(L))
+    return out[:a.shape[0]]
 
 
 def host_oligo_overlap(assay, pool):

@@ -3,9 +3,12 @@ device primitives: trial generation on the host (pcr_host_move_trials), PCR::is_
 (pcr_thermo, no dimer check), coverage of every surviving trial in one call per sequence set
 (pcr_move_coverage), then the reference's coverage-bound shortcut and Score comparison.
 
-Non-multiplex (empty pool): Score.oligo_overlap stays 0.  The word DBs of the target and background
-sets must have been built for the current trial assays (Screener.select_words on each set), as
-optimize() is called inside main.cpp's per-iteration DB build.
+optimize() also runs with opt.use_multiplex (`pool` = the assays designed so far, the multiplex background
+keys loaded with Screener.multiplex_load): the multiplex background coverage joins the background term
+(pcr_multiplex_coverage), Score.oligo_overlap is the oligo-reuse term (pcr_host_pool_overlaps), the coverage
+bound turns from `<= 0` to `< 0`.  The word DBs of the target and background sets must have been built for
+the current trial assays (Screener.select_words on each set), as optimize() is called inside main.cpp's
+per-iteration DB build.
 """
 import numpy as np
 
@@ -15,6 +18,11 @@ from . import words as W
 INCREASE_DEGENERACY, DECREASE_DEGENERACY, TRIM5, TRIM3, GROW5, GROW3 = range(6)
 
 EMPTY_SCORE = (np.float32(-1.0e6), np.float32(1.0e6), np.float32(0.0))     # Score(), pcramp.h:176-179
+REUSE_BONUS = np.float32(10.0)                                              # MULTIPLEX_OLIGO_REUSE_BONUS, assay.h:19
+
+
+def _reuse(v):
+    return REUSE_BONUS if np.float32(v) == np.float32(1.0) else np.float32(v)
 
 
 def _accuracy(sc):
@@ -98,11 +106,12 @@ DEFAULT_MOVES = (INCREASE_DEGENERACY, DECREASE_DEGENERACY, TRIM5, GROW5, TRIM3, 
 def _evaluate_iteration(scr, approx, move_list, degen=1, primer_min=18, primer_max=25, salt=0.05, primer_strand=9.0e-7,
                         tm_min=50.0, tm_max=70.0, max_hairpin=40.0, target_threshold=1.0, search_multiplier=0.9, amp_min=80,
                         amp_max=200, use_taq_mama=False, bg_threshold=0.8, bg_multiplier=0.9, bg_amp_min=0, bg_amp_max=2000,
-                        have_background=True):
+                        have_background=True, pool=None):
     """Everything one optimize() iteration needs from the device, in five calls instead of three per move: the
     trial words of every move of both oligos, their is_valid flags, their target and background coverage.
     Coverage does not depend on the running score threshold, so the moves can be decided on the host afterwards
-    in the reference's order.  -> {(side, move): [(word, valid, tc, bc), ...]}"""
+    in the reference's order.  With `pool` (use_multiplex) also the multiplex background coverage and the largest
+    overlap with a pooled oligo of every trial.  -> {(side, move): [(word, valid, tc, bc, mc, pov), ...]}"""
     per = {}
     flat = {0: [], 1: []}
     for side in (0, 1):
@@ -129,31 +138,46 @@ def _evaluate_iteration(scr, approx, move_list, degen=1, primer_min=18, primer_m
                                                use_taq_mama, which=api.BACKGROUND, bits=False)
             else:
                 bcov = np.zeros(len(live), np.float32)
-        it = iter(zip(tcov, bcov))
+        mcov = pov = np.zeros(len(live), np.float32)
+        if live and pool is not None:
+            mcov = scr.multiplex_coverage(approx, side, live, bg_threshold, use_taq_mama)
+            pov = api.host_pool_overlaps(live, pool)
+        it = iter(zip(tcov, bcov, mcov, pov))
         rows = []
         for w, v in zip(words, valid):
             if v:
-                tc, bc = next(it)
-                rows.append((w, True, np.float32(tc), np.float32(bc)))
+                tc, bc, mc, po = next(it)
+                rows.append((w, True, np.float32(tc), np.float32(bc), np.float32(mc), np.float32(po)))
             else:
-                rows.append((w, False, None, None))
+                rows.append((w, False, None, None, None, None))
         for mv in move_list:
             lo, n = per[(side, mv)]
             out[(side, mv)] = rows[lo:lo + n]
     return out
 
 
-def _decide_move(rows, score_threshold):
+def _decide_move(rows, score_threshold, move=None, partial=None):
     """One move function's loop over its trials (optimize_pcr.cpp): is_valid gate, coverage-bound shortcut
-    (:95-109), Score comparison.  rows: [(word, valid, tc, bc)]."""
+    (:95-109), Score comparison.  rows: [(word, valid, tc, bc, mc, pov)].  partial is not None = use_multiplex:
+    the reuse term of the oligo that is not edited (:27-53); the bound is then `< 0`, the multiplex coverage
+    joins the background term and the trial's reuse term is added -- increase_degeneracy alone never resets
+    trial_score.oligo_overlap between its trials (:133-145), so there the maximum starts from the previous
+    trial's total."""
     best_w, best = (0, 0), EMPTY_SCORE
-    for w, valid, tc, bc in rows:
+    carried = np.float32(0.0)
+    for w, valid, tc, bc, mc, pov in rows:
         if not valid:
             continue
         bound = np.float32(np.float32(tc) + np.float32(score_threshold[1])) - np.float32(score_threshold[0])
-        if bound <= 0.0:
+        if (bound < 0.0) if partial is not None else (bound <= 0.0):
             continue
-        trial = (np.float32(tc), np.float32(bc), np.float32(0.0))
+        ov = np.float32(0.0)
+        if partial is not None:
+            bc = np.float32(np.float32(bc) + np.float32(mc))
+            ov = max(np.float32(pov), carried) if move == INCREASE_DEGENERACY else np.float32(pov)
+            ov = np.float32(_reuse(ov) + np.float32(partial))
+            carried = ov
+        trial = (np.float32(tc), np.float32(bc), ov)
         if score_gt(trial, best):
             best, best_w = trial, w
     return best_w, best
@@ -167,6 +191,10 @@ def optimize(scr, pair, move_list=DEFAULT_MOVES, **opts):
     go to the lower degeneracy, :133-135), the winner re-centred and installed (:152-154); stops when nothing
     improves, when the score drops, or when an assay repeats (:196-202).  The device is asked once per
     iteration for all trial words of all moves (`_evaluate_iteration`).  -> (best pair, Score)."""
+    pool = opts.get("pool")                                            # not None = opt.use_multiplex
+    if pool is not None:
+        pool = [(tuple(int(x) for x in f), tuple(int(x) for x in r)) for f, r in pool]
+        opts = dict(opts, pool=pool)
     cov_kw = {k: opts[k] for k in ("target_threshold", "search_multiplier", "amp_min", "amp_max", "use_taq_mama",
                                    "bg_threshold", "bg_multiplier", "bg_amp_min", "bg_amp_max", "have_background") if k in opts}
     best = (tuple(int(x) for x in pair[0]), tuple(int(x) for x in pair[1]))
@@ -175,15 +203,23 @@ def optimize(scr, pair, move_list=DEFAULT_MOVES, **opts):
     previous = {approx}
     while True:
         tc, bc = base_score(scr, approx, **cov_kw)
-        approx_score = (tc, bc, np.float32(0.0))
+        ov = np.float32(0.0)
+        if pool is not None:                                           # optimize.cpp:79-97
+            mc = scr.multiplex_coverage(approx, 0, [approx[0]], opts.get("bg_threshold", 0.8), opts.get("use_taq_mama", False))[0]
+            bc = np.float32(np.float32(bc) + np.float32(mc))
+            ov = api.host_oligo_overlap(approx, pool)
+        approx_score = (tc, bc, ov)
         if score_lt(approx_score, best_score):
             break
         best_score, best = approx_score, approx
         evaluated = _evaluate_iteration(scr, approx, move_list, **opts)
         local_seq, local_oligo, local_score, improved = (0, 0), None, approx_score, False
         for side in (0, 1):
+            partial = None
+            if pool is not None:                                       # the other oligo's reuse term, e.g. optimize_pcr.cpp:27-53
+                partial = _reuse(api.host_pool_overlaps([approx[1 - side]], pool)[0])
             for mv in move_list:
-                w, sc = _decide_move(evaluated[(side, mv)], local_score)
+                w, sc = _decide_move(evaluated[(side, mv)], local_score, mv, partial)
                 if score_gt(sc, local_score) or (score_eq(sc, local_score) and W.word_degeneracy(w) < W.word_degeneracy(local_seq)):
                     local_score, local_seq, local_oligo, improved = sc, w, side, True
         if not improved:

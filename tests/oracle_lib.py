@@ -318,6 +318,27 @@ def optimize(lib, target_session, background_session, pair, moves=(0, 1, 2, 4, 3
     return ((int(flat[0]), int(flat[1])), (int(flat[2]), int(flat[3]))), tuple(float(x) for x in sc)
 
 
+def optimize_multiplex(lib, target_session, background_session, amplicon_session, pool, pair, moves=(0, 1, 2, 4, 3, 5), **mo):
+    """optimize() with opt.use_multiplex: multiplex background = pack of amplicon_session's sequences, pool = assays
+    designed so far -> (best pair, (tc, bc incl. the multiplex term, oligo_overlap))."""
+    o = dict(DEFAULT_MOVE_OPTIONS)
+    o.update(mo)
+    opts = MoveOptions(**o)
+    a = pairs_array([pair]).copy()
+    pw = pairs_array(pool) if len(pool) else np.zeros((1, 4), dtype=np.uint64)
+    mv = np.array(list(moves), dtype=np.int32)
+    sc = np.zeros(3, dtype=np.float32)
+    fn = getattr(lib.lib, lib.prefix + "optimize_multiplex")
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_int,
+                   C.POINTER(MoveOptions), C.c_void_p]
+    rc = fn(target_session.h, background_session.h if background_session is not None else None, amplicon_session.h,
+            pw.ctypes.data, len(pool), a.ctypes.data, mv.ctypes.data, len(mv), C.byref(opts), sc.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(target_session.f("session_error")(target_session.h))
+    r = a[0]
+    return ((int(r[0]), int(r[1])), (int(r[2]), int(r[3]))), tuple(float(x) for x in sc)
+
+
 class SamplerOptions(C.Structure):
     _fields_ = [("primer_min", C.c_int), ("primer_max", C.c_int), ("amp_min", C.c_int), ("amp_max", C.c_int),
                 ("max_degen", C.c_double), ("salt", C.c_float), ("primer_strand", C.c_float), ("tm_min", C.c_float),

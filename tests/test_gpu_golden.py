@@ -153,3 +153,32 @@ def test_multiplex_golden(ci):
             assert np.array_equal(got, np.array(cov, np.float32)), (pi, side, thr)
     finally:
         d.close()
+
+
+@pytest.mark.parametrize("ci", range(3))
+def test_multiplex_optimize_golden(ci):
+    """pcramp_amd.moves.optimize with opt.use_multiplex against the reference's own optimize()
+    (tests/golden/multiplex_optimize.json): final assay and Score incl. the oligo-reuse term."""
+    from pcramp_amd import moves
+    with open(os.path.join(G, "multiplex_optimize.json")) as f:
+        c = json.load(f)["cases"][ci]
+    o, mo = c["options"], c["move_options"]
+    pw = lambda p: ((int(p[0], 16), int(p[1], 16)), (int(p[2], 16), int(p[3], 16)))
+    pool, cands = [pw(p) for p in c["pool"]], [pw(p) for p in c["candidates"]]
+    d = api.Screener(0)
+    try:
+        d.load_texts(c["seqs"], c["weights"], which=api.TARGET)
+        d.load_texts(c["backgrounds"], [1.0] * len(c["backgrounds"]), which=api.BACKGROUND)
+        d.multiplex_load(c["amplicons"], o["min_primer"])
+        thr = float(np.float32(o["target_threshold"]) * np.float32(o["search_multiplier"]))
+        d.select_words(cands + pool, thr, o["min_primer"], o["optimize_5"], o["optimize_3"], which=api.TARGET)
+        d.select_words(cands + pool, float(np.float32(c["bg_select_threshold"])), c["bg_min_len"], o["optimize_5"], o["optimize_3"],
+                       which=api.BACKGROUND)
+        for pi, use_pool, bp, sc in c["optimize"]:
+            got, s = moves.optimize(d, cands[pi], pool=(pool if use_pool else []), target_threshold=o["target_threshold"],
+                                    search_multiplier=o["search_multiplier"], amp_min=o["amp_min"], amp_max=o["amp_max"],
+                                    use_taq_mama=bool(o["use_taq_mama"]), **mo)
+            assert got == pw(bp), (pi, use_pool)
+            assert tuple(float(x) for x in s) == tuple(float(np.float32(x)) for x in sc), (pi, use_pool)
+    finally:
+        d.close()

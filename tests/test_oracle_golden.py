@@ -181,3 +181,26 @@ def test_multiplex_coverage(oracle, ci):
         got, k = sess.multiplex_coverage(pairs[pi], side, [_hw(v) for v in var], thr, c["use_taq_mama"])
         assert k == nk
         assert np.array_equal(got, np.array(cov, np.float32)), (pi, side, thr)
+
+
+@pytest.mark.parametrize("ci", range(3))
+def test_multiplex_optimize(oracle, ci):
+    """optimize() with opt.use_multiplex: the reference's final assay and Score."""
+    from oracle_lib import optimize_multiplex
+    c = load("multiplex_optimize")["cases"][ci]
+    sess = {k: c["options"][k] for k in ("target_threshold", "use_taq_mama")}
+    ts, bs, ams = oracle.session(**c["options"]), oracle.session(**c["options"]), oracle.session(**sess)
+    for q, wt in zip(c["seqs"], c["weights"]):
+        ts.add_target(q, wt)
+    for q in c["backgrounds"]:
+        bs.add_target(q, 1.0)
+    for q in c["amplicons"]:
+        ams.add_target(q, 1.0)
+    pw = lambda p: (_hw(p[:2]), _hw(p[2:]))
+    pool, cands = [pw(p) for p in c["pool"]], [pw(p) for p in c["candidates"]]
+    ts.select(cands + pool)
+    bs.select(cands + pool, threshold=c["bg_select_threshold"], min_len_override=c["bg_min_len"])
+    for pi, use_pool, bp, sc in c["optimize"]:
+        got = optimize_multiplex(oracle, ts, bs, ams, pool if use_pool else [], cands[pi], **c["move_options"])
+        assert got[0] == pw(bp), (pi, use_pool)
+        assert got[1] == tuple(float(np.float32(x)) for x in sc), (pi, use_pool)

@@ -549,3 +549,32 @@ def test_multiplex_background_coverage(oracle, reference, taq):
                 assert np.array_equal(co, cr), (p, side, thr)
                 nonzero += int(np.count_nonzero(co))
     assert nonzero > 100
+
+
+@pytest.mark.parametrize("case", [dict(), dict(degen=8), dict(degen=16, target_threshold=0.9, use_taq_mama=1),
+                                  dict(degen=4, tm_min=-100.0, tm_max=200.0, max_hairpin=500.0)])
+def test_optimize_loop_multiplex(oracle, reference, case):
+    """optimize() with opt.use_multiplex (multiplex background keys, oligo reuse term, the '< 0' coverage bound,
+    increase_degeneracy's carried overlap): the reference's own loop against the oracle's restatement."""
+    from oracle_lib import optimize_multiplex
+    from testdata import multiplex_design_case
+    case = dict(case)
+    sess = {k: case.pop(k) for k in ("target_threshold", "use_taq_mama") if k in case}
+    rng = random.Random(77 + len(case) + 10 * len(sess))
+    seqs, bgs, amps, pool, cands = multiplex_design_case(rng, reference)
+    to, tr = _sessions(oracle, reference, seqs, [1.0 + 0.25 * (i % 3) for i in range(len(seqs))], optimize_5=1, optimize_3=1, **sess)
+    bo, br = _sessions(oracle, reference, bgs, None, optimize_5=1, optimize_3=1, **sess)
+    ao, ar = _sessions(oracle, reference, amps, None, **sess)
+    allp = cands + pool
+    assert to.select(allp) == tr.select(allp)
+    bthr = float(np.float32(0.8) * np.float32(0.9))
+    assert bo.select(allp, threshold=bthr, min_len_override=16) == br.select(allp, threshold=bthr, min_len_override=16)
+    changed = with_overlap = 0
+    for p in cands:
+        for pl in (pool, []):
+            ro = optimize_multiplex(oracle, to, bo, ao, pl, p, **case)
+            rr = optimize_multiplex(reference, tr, br, ar, pl, p, **case)
+            assert ro == rr, (p, ro, rr)
+            changed += ro[0] != p
+            with_overlap += ro[1][2] > 0
+    assert changed > 0 and with_overlap > 0

@@ -122,3 +122,35 @@ def multiplex_case(rng, words_mod, lib, n_amp=12):
         f, r = primer(), primer() if rng.random() < 0.7 else rand_seq(rng, 20)
         pairs.append((lib.centered_word(f), lib.centered_word(r)))
     return amps, pairs
+
+
+def multiplex_design_case(rng, lib, seed_shift=0):
+    """A small multiplex design state: target families, backgrounds, assays designed so far (the pool) with the
+    amplicons they produced (the multiplex background), and candidate assays -- some reuse a pooled oligo, some
+    sit on a pooled amplicon, some were damaged so that the search has something to repair."""
+    seqs = family_targets(rng, 3, 6, 500, div=0.06)
+    bgs = [mutate(rng, s, 0.12) for s in seqs[::4]] + [rand_seq(rng, 400)]
+    pool_txt, amps = [], []
+    while len(pool_txt) < 3:
+        t = rng.choice(seqs)
+        p = sample_pair(rng, t)
+        if not p:
+            continue
+        f, r = p
+        i, j = t.find(f), t.find(revcomp(r))
+        if i < 0 or j < 0 or j <= i:
+            continue
+        pool_txt.append(p)
+        amps.append(t[i + len(f) - 5:j + 5])                           # primers trimmed, 5 bases of padding (pcr_assay.cpp:489-497)
+    cands = []
+    while len(cands) < 4:
+        p = sample_pair(rng, rng.choice(seqs))
+        if p:
+            cands.append(p)
+    cands.append((pool_txt[0][0], cands[0][1]))                        # reuses a pooled forward primer
+    cands.append((cands[1][0], pool_txt[1][0]))                        # reverse oligo identical to a pooled oligo
+    a = amps[0]
+    cands.append((a[8:28], revcomp(a[len(a) - 30:len(a) - 10])))       # sits on an accepted amplicon
+    cands.append((mutate(rng, cands[2][0], 0.1), mutate(rng, cands[2][1], 0.1)))
+    w = lambda x: lib.centered_word(x)
+    return seqs, bgs, amps, [(w(f), w(r)) for f, r in pool_txt], [(w(f), w(r)) for f, r in cands]
