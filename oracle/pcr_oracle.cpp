@@ -898,18 +898,43 @@ int orc_optimize(orc_session *t, orc_session *b, uint64_t pair_inout[4], const i
 	return optimize_impl(t, b, nullptr, pair_inout, moves, n_moves, mo, out_score, iterations_out);
 }
 
-// optimize() with opt.use_multiplex: `amplicons` = the accepted assays' amplicons (their pack is the multiplex
-// background DB, main.cpp:989-1001), pool = n_pool x {F[2], R[2]} = the assays designed so far.
-int orc_optimize_multiplex(orc_session *t, orc_session *b, orc_session *amplicons, const uint64_t *pool, unsigned n_pool,
-	uint64_t pair_inout[4], const int *moves, int n_moves, const orc_move_options *mo, float out_score[3])
+static void build_mx(Mx &mx, orc_session *amplicons, const uint64_t *pool, unsigned n_pool)
 {
-	Mx mx;
 	std::vector<Entry> db;
 	for(size_t i = 0;i < amplicons->seq.size();++i)
 		pack(amplicons->seq[i], (unsigned)i, amplicons->opt.pack_max_degen, 0.0f, 1.0f, (unsigned)amplicons->opt.min_primer, db);
 	std::stable_sort(db.begin(), db.end(), entry_key_less);
 	for(const Entry &e : db){ if(mx.keys.empty() || !(mx.keys.back() == e.w)) mx.keys.push_back(e.w); }
 	for(unsigned i = 0;i < n_pool;++i){ mx.pool.push_back(load_word(pool + 4*i)); mx.pool.push_back(load_word(pool + 4*i + 2)); }
+}
+
+// One move with opt.use_multiplex, the base Score (incl. the multiplex terms) as the score threshold.
+int orc_optimization_move_multiplex(orc_session *t, orc_session *b, orc_session *amplicons, const uint64_t *pool, unsigned n_pool,
+	const uint64_t pair[4], int move, int side, const orc_move_options *mo, uint64_t out_word[2], float out_score[3], float base_score_out[3])
+{
+	try{
+		Mx mx;
+		build_mx(mx, amplicons, pool, n_pool);
+		const W F = load_word(pair), R = load_word(pair + 2);
+		MoveState m;
+		move_state(m, t, b, F, R, mo, &mx);
+		if(base_score_out){ base_score_out[0] = m.base.tc; base_score_out[1] = m.base.bc; base_score_out[2] = m.base.ov; }
+		W best_w; ScoreO best;
+		move_eval(m, t, b, F, R, move, side, mo, m.base, best_w, best, &mx);
+		out_word[0] = best_w.b[0]; out_word[1] = best_w.b[1];
+		out_score[0] = best.tc; out_score[1] = best.bc; out_score[2] = best.ov;
+		return 0;
+	}
+	catch(const char *e){ t->err = e; return -1; }
+}
+
+// optimize() with opt.use_multiplex: `amplicons` = the accepted assays' amplicons (their pack is the multiplex
+// background DB, main.cpp:989-1001), pool = n_pool x {F[2], R[2]} = the assays designed so far.
+int orc_optimize_multiplex(orc_session *t, orc_session *b, orc_session *amplicons, const uint64_t *pool, unsigned n_pool,
+	uint64_t pair_inout[4], const int *moves, int n_moves, const orc_move_options *mo, float out_score[3])
+{
+	Mx mx;
+	build_mx(mx, amplicons, pool, n_pool);
 	return optimize_impl(t, b, &mx, pair_inout, moves, n_moves, mo, out_score, nullptr);
 }
 

@@ -112,6 +112,8 @@ int orc_optimize(orc_session *t, orc_session *b, uint64_t pair_inout[4], const i
 // candidates of `base`, then per trial word of the oligo on `side` update_identity + the distinct-key count.
 int orc_multiplex_coverage(orc_session *s, const uint64_t base[4], int side, const uint64_t *variants, unsigned n_variants,
 	float background_threshold, int use_taq_mama, float *cov_out, unsigned *n_keys_out);
+int orc_optimization_move_multiplex(orc_session *t, orc_session *b, orc_session *amplicons, const uint64_t *pool, unsigned n_pool,
+	const uint64_t pair[4], int move, int side, const orc_move_options *mo, uint64_t out_word[2], float out_score[3], float base_score_out[3]);
 // optimize() with opt.use_multiplex (optimize.cpp:79-97, the multiplex blocks of every move in optimize_pcr.cpp)
 int orc_optimize_multiplex(orc_session *t, orc_session *b, orc_session *amplicons, const uint64_t *pool, unsigned n_pool,
 	uint64_t pair_inout[4], const int *moves, int n_moves, const orc_move_options *mo, float out_score[3]);

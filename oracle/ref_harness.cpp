@@ -462,6 +462,72 @@ int ref_optimize(RefSession *t, RefSession *b, uint64_t pair_inout[4], const int
 	catch(...){ t->last_error = "unknown"; return -2; }
 }
 
+// One move with opt.use_multiplex: candidates / identity tables / Score of the base assay as optimize() builds
+// them (optimize.cpp:61-97), then the reference's own optimization_move().
+int ref_optimization_move_multiplex(RefSession *t, RefSession *b, RefSession *amplicons, const uint64_t *pool_words, unsigned n_pool,
+	const uint64_t pair[4], int move, int side, const RefMoveOptions *mo, uint64_t out_word[2], float out_score[3], float base_score_out[3])
+{
+	try{
+		Options opt = t->opt;
+		opt.degen = mo->degen;
+		opt.primer_range = make_pair(mo->primer_min, mo->primer_max);
+		opt.salt = mo->salt; opt.primer_strand = mo->primer_strand;
+		opt.primer_tm_range = make_pair(mo->tm_min, mo->tm_max);
+		opt.max_hairpin = mo->max_hairpin;
+		opt.background_threshold = mo->bg_threshold;
+		opt.background_search_multiplier = mo->bg_multiplier;
+		opt.background_amplicon_range = make_pair(mo->bg_amp_min, mo->bg_amp_max);
+		opt.use_multiplex = true;
+		const vector<Word> no_keys;
+		const MULTIMAP<Word, WordMatch> no_db;
+		const deque<Sequence> no_seq;
+		const vector<Word> &bkeys = b ? b->target_keys : no_keys;
+		MULTIMAP<Word, WordMatch> mdb;
+		deque<Sequence> mseq;
+		for(deque<Sequence>::const_iterator i = amplicons->target_seq.begin();i != amplicons->target_seq.end();++i){
+			i->pack(mdb, mseq.size(), amplicons->opt.pack_max_degen, 0.0, 1.0, amplicons->opt.min_oligo_length());
+			mseq.push_back(*i);
+		}
+		mdb.sort();
+		const vector<Word> mkeys = keys(mdb);
+		deque<PCR> pool(n_pool);
+		for(unsigned i = 0;i < n_pool;++i){
+			pool[i].oligo( FORWARD, word_from(pool_words + 4*i) );
+			pool[i].oligo( REVERSE, word_from(pool_words + 4*i + 2) );
+		}
+		PCR p;
+		p.oligo( FORWARD, word_from(pair) );
+		p.oligo( REVERSE, word_from(pair + 2) );
+		p.collect_target_candidates(t->target_keys, t->target_db, t->target_seq, opt);
+		p.collect_background_candidates(bkeys, b ? b->target_db : no_db, b ? b->target_seq : no_seq, opt);
+		p.update_target_candidates(t->target_keys, opt.use_taq_mama);
+		p.update_background_candidates(bkeys, opt.use_taq_mama);
+		Score base;
+		base.target_coverage = p.compute_target_coverage(opt.target_threshold);
+		base.background_coverage = p.compute_background_coverage(opt.background_threshold);
+		p.collect_multiplex_background_candidates(mkeys, mdb, mseq, opt);
+		p.update_multiplex_background_candidates(mkeys, opt.use_taq_mama);
+		base.background_coverage += p.compute_multiplex_background_coverage(opt.background_threshold);
+		base.oligo_overlap = p.compute_oligo_overlap(pool);
+		if(base_score_out){ base_score_out[0] = base.target_coverage; base_score_out[1] = base.background_coverage; base_score_out[2] = base.oligo_overlap; }
+		NucCruc melt;
+		prefill(melt);
+		melt.fast_alignment(true);
+		melt.salt(opt.salt);
+		const Move mv[6] = { IncreaseDegeneracy, DecreaseDegeneracy, Trim5, Trim3, Grow5, Grow3 };
+		if(move < 0 || move > 5) throw "unknown move";
+		const std::pair<Word, Score> r = optimization_move(mv[move], (side == 0) ? FORWARD : REVERSE, p,
+			t->target_keys, opt.target_threshold, bkeys, opt.background_threshold, mkeys, base, melt, pool, opt);
+		unsigned char buf[16];
+		r.first.mpi_pack(buf);
+		memcpy(out_word, buf, 16);
+		out_score[0] = r.second.target_coverage; out_score[1] = r.second.background_coverage; out_score[2] = r.second.oligo_overlap;
+		return 0;
+	}
+	catch(const char *e){ t->last_error = e; return -1; }
+	catch(...){ t->last_error = "unknown"; return -2; }
+}
+
 // optimize() with opt.use_multiplex: multiplex background DB = pack of the `amplicons` session's sequences
 // (main.cpp:989-1001), pool = the assays designed so far.
 int ref_optimize_multiplex(RefSession *t, RefSession *b, RefSession *amplicons, const uint64_t *pool_words, unsigned n_pool,

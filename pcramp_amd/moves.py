@@ -52,8 +52,9 @@ def base_score(scr, pair, target_threshold=1.0, search_multiplier=0.9, amp_min=8
 def optimization_move(scr, pair, move, side, score_threshold=None, degen=1, primer_min=18, primer_max=25, salt=0.05,
                       primer_strand=9.0e-7, tm_min=50.0, tm_max=70.0, max_hairpin=40.0, target_threshold=1.0,
                       search_multiplier=0.9, amp_min=80, amp_max=200, use_taq_mama=False, bg_threshold=0.8,
-                      bg_multiplier=0.9, bg_amp_min=0, bg_amp_max=2000, have_background=True):
-    """optimization_move (optimize.cpp:303-352) for one oligo of `pair` (side 0 = F, 1 = R).
+                      bg_multiplier=0.9, bg_amp_min=0, bg_amp_max=2000, have_background=True, pool=None):
+    """optimization_move (optimize.cpp:303-352) for one oligo of `pair` (side 0 = F, 1 = R).  pool is not None =
+    opt.use_multiplex (score_threshold then carries the multiplex terms: see multiplex_base_score).
 
     -> (word, (target_coverage, background_coverage, oligo_overlap)); the empty word (0, 0) and Score()
     if no trial survives, as the reference's move functions return."""
@@ -61,7 +62,7 @@ def optimization_move(scr, pair, move, side, score_threshold=None, degen=1, prim
               use_taq_mama=use_taq_mama, bg_threshold=bg_threshold, bg_multiplier=bg_multiplier, bg_amp_min=bg_amp_min,
               bg_amp_max=bg_amp_max, have_background=have_background)
     if score_threshold is None:
-        score_threshold = base_score(scr, pair, **kw)
+        score_threshold = multiplex_base_score(scr, pair, pool, **kw) if pool is not None else base_score(scr, pair, **kw)
     trials = api.host_move_trials(pair[side], move, degen, primer_min, primer_max)
     best_w, best = (0, 0), EMPTY_SCORE
     if not trials:
@@ -78,14 +79,23 @@ def optimization_move(scr, pair, move, side, score_threshold=None, degen=1, prim
                                        which=api.BACKGROUND, bits=False)
     else:
         bcov = np.zeros(len(live), np.float32)
-    for t, tc, bc in zip(live, tcov, bcov):
-        bound = np.float32(np.float32(tc) + np.float32(score_threshold[1])) - np.float32(score_threshold[0])   # optimize_pcr.cpp:95-97
-        if bound <= 0.0:                                                                                        # :102-109
-            continue
-        trial = (np.float32(tc), np.float32(bc), np.float32(0.0))
-        if score_gt(trial, best):
-            best, best_w = trial, t
-    return best_w, best
+    mcov = pov = np.zeros(len(live), np.float32)
+    partial = None
+    if pool is not None:
+        mcov = scr.multiplex_coverage(pair, side, live, bg_threshold, use_taq_mama)
+        pov = api.host_pool_overlaps(live, pool)
+        partial = _reuse(api.host_pool_overlaps([pair[1 - side]], pool)[0])
+    rows = [(t, True, np.float32(tc), np.float32(bc), np.float32(mc), np.float32(po))
+            for t, tc, bc, mc, po in zip(live, tcov, bcov, mcov, pov)]
+    return _decide_move(rows, score_threshold, move, partial)
+
+
+def multiplex_base_score(scr, pair, pool, **kw):
+    """Score of the unmodified assay with opt.use_multiplex (optimize.cpp:72-97): (tc, bc + multiplex coverage,
+    oligo_overlap)."""
+    tc, bc = base_score(scr, pair, **kw)
+    mc = scr.multiplex_coverage(pair, 0, [pair[0]], kw.get("bg_threshold", 0.8), kw.get("use_taq_mama", False))[0]
+    return tc, np.float32(np.float32(bc) + np.float32(mc)), api.host_oligo_overlap(pair, pool)
 
 
 def score_lt(a, b):
@@ -202,13 +212,10 @@ def optimize(scr, pair, move_list=DEFAULT_MOVES, **opts):
     best_score = EMPTY_SCORE
     previous = {approx}
     while True:
-        tc, bc = base_score(scr, approx, **cov_kw)
-        ov = np.float32(0.0)
         if pool is not None:                                           # optimize.cpp:79-97
-            mc = scr.multiplex_coverage(approx, 0, [approx[0]], opts.get("bg_threshold", 0.8), opts.get("use_taq_mama", False))[0]
-            bc = np.float32(np.float32(bc) + np.float32(mc))
-            ov = api.host_oligo_overlap(approx, pool)
-        approx_score = (tc, bc, ov)
+            approx_score = multiplex_base_score(scr, approx, pool, **cov_kw)
+        else:
+            approx_score = base_score(scr, approx, **cov_kw) + (np.float32(0.0),)
         if score_lt(approx_score, best_score):
             break
         best_score, best = approx_score, approx

@@ -318,6 +318,27 @@ def optimize(lib, target_session, background_session, pair, moves=(0, 1, 2, 4, 3
     return ((int(flat[0]), int(flat[1])), (int(flat[2]), int(flat[3]))), tuple(float(x) for x in sc)
 
 
+def optimization_move_multiplex(lib, target_session, background_session, amplicon_session, pool, pair, move, side, **mo):
+    """One local-search move with opt.use_multiplex -> ((w0, w1), (tc, bc, overlap), base (tc, bc, overlap))."""
+    o = dict(DEFAULT_MOVE_OPTIONS)
+    o.update(mo)
+    opts = MoveOptions(**o)
+    a = pairs_array([pair])
+    pw = pairs_array(pool) if len(pool) else np.zeros((1, 4), dtype=np.uint64)
+    w = np.zeros(2, dtype=np.uint64)
+    sc = np.zeros(3, dtype=np.float32)
+    base = np.zeros(3, dtype=np.float32)
+    fn = getattr(lib.lib, lib.prefix + "optimization_move_multiplex")
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_int, C.c_int, C.POINTER(MoveOptions),
+                   C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = fn(target_session.h, background_session.h if background_session is not None else None, amplicon_session.h,
+            pw.ctypes.data, len(pool), a.ctypes.data, int(move), int(side), C.byref(opts), w.ctypes.data, sc.ctypes.data,
+            base.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(target_session.f("session_error")(target_session.h))
+    return (int(w[0]), int(w[1])), tuple(float(x) for x in sc), tuple(float(x) for x in base)
+
+
 def optimize_multiplex(lib, target_session, background_session, amplicon_session, pool, pair, moves=(0, 1, 2, 4, 3, 5), **mo):
     """optimize() with opt.use_multiplex: multiplex background = pack of amplicon_session's sequences, pool = assays
     designed so far -> (best pair, (tc, bc incl. the multiplex term, oligo_overlap))."""

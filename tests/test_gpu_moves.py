@@ -268,3 +268,50 @@ def test_multiplex_coverage_matches_oracle(oracle, taq):
         assert d.multiplex_coverage(pairs[0], 0, [pairs[0][0]]).tolist() == [0.0]
     finally:
         d.close()
+
+
+@pytest.mark.parametrize("case", [dict(degen=8), dict(degen=16, use_taq_mama=1)])
+def test_optimization_move_multiplex_matches_oracle(oracle, case):
+    """Every move x both oligos with opt.use_multiplex (multiplex background term, reuse term, '< 0' bound):
+    trial word and Score identical to the oracle (itself == the reference's own optimization_move())."""
+    from pcramp_amd import moves
+    from oracle_lib import optimization_move_multiplex, DEFAULT_MOVE_OPTIONS
+    from testdata import multiplex_design_case
+    case = dict(case)
+    taq = case.pop("use_taq_mama", 0)
+    rng = random.Random(929 + taq)
+    seqs, bgs, amps, pool, cands = multiplex_design_case(rng, oracle)
+    o = dict(target_threshold=1.0, search_multiplier=0.9, amp_min=80, amp_max=200, use_taq_mama=taq, pack_max_degen=256,
+             pack_min_gc=0.0, pack_max_gc=1.0, min_primer=18, optimize_5=1, optimize_3=1)
+    ts, bs, ams = oracle.session(**o), oracle.session(**o), oracle.session(use_taq_mama=taq)
+    for q in seqs:
+        ts.add_target(q, 1.0)
+    for q in bgs:
+        bs.add_target(q, 1.0)
+    for q in amps:
+        ams.add_target(q, 1.0)
+    allp = cands + pool
+    bthr = float(np.float32(0.8) * np.float32(0.9))
+    ts.select(allp)
+    bs.select(allp, threshold=bthr, min_len_override=16)
+    d = api.Screener(0)
+    try:
+        d.load_texts(seqs, [1.0] * len(seqs))
+        d.load_texts(bgs, [1.0] * len(bgs), which=api.BACKGROUND)
+        d.multiplex_load(amps, 18)
+        d.select_words(allp, float(np.float32(1.0) * np.float32(0.9)), 18, True, True)
+        d.select_words(allp, bthr, 16, True, True, which=api.BACKGROUND)
+        mo = dict(DEFAULT_MOVE_OPTIONS)
+        mo.update(case)
+        found = 0
+        for p in cands:
+            for side in (0, 1):
+                for move in range(6):
+                    want = optimization_move_multiplex(oracle, ts, bs, ams, pool, p, move, side, **case)
+                    w, sc = moves.optimization_move(d, p, move, side, pool=pool, use_taq_mama=bool(taq), **mo)
+                    assert w == want[0], (p, side, move)
+                    assert tuple(float(x) for x in sc) == want[1], (p, side, move)
+                    found += w != (0, 0)
+        assert found > 20
+    finally:
+        d.close()

@@ -578,3 +578,31 @@ def test_optimize_loop_multiplex(oracle, reference, case):
             changed += ro[0] != p
             with_overlap += ro[1][2] > 0
     assert changed > 0 and with_overlap > 0
+
+
+@pytest.mark.parametrize("case", [dict(degen=8), dict(degen=16, target_threshold=0.9, use_taq_mama=1)])
+def test_optimization_move_multiplex(oracle, reference, case):
+    """Every move x both oligos with opt.use_multiplex: trial word, Score and base Score (reference's own
+    optimization_move() against the oracle)."""
+    from oracle_lib import optimization_move_multiplex
+    from testdata import multiplex_design_case
+    case = dict(case)
+    sess = {k: case.pop(k) for k in ("target_threshold", "use_taq_mama") if k in case}
+    rng = random.Random(515 + len(sess))
+    seqs, bgs, amps, pool, cands = multiplex_design_case(rng, reference)
+    to, tr = _sessions(oracle, reference, seqs, None, optimize_5=1, optimize_3=1, **sess)
+    bo, br = _sessions(oracle, reference, bgs, None, optimize_5=1, optimize_3=1, **sess)
+    ao, ar = _sessions(oracle, reference, amps, None, **sess)
+    allp = cands + pool
+    to.select(allp); tr.select(allp)
+    bthr = float(np.float32(0.8) * np.float32(0.9))
+    bo.select(allp, threshold=bthr, min_len_override=16); br.select(allp, threshold=bthr, min_len_override=16)
+    found = 0
+    for p in cands:
+        for side in (0, 1):
+            for move in range(6):
+                ro = optimization_move_multiplex(oracle, to, bo, ao, pool, p, move, side, **case)
+                rr = optimization_move_multiplex(reference, tr, br, ar, pool, p, move, side, **case)
+                assert ro == rr, (p, side, move, ro, rr)
+                found += ro[0] != (0, 0)
+    assert found > 20
