@@ -262,6 +262,25 @@ int pcr_multiplex_load(pcr_ctx *ctx, const uint8_t *packed4, const uint64_t *byt
 int pcr_multiplex_coverage(pcr_ctx *ctx, const pcr_pair *base, int side, const pcr_word128 *variants, uint32_t n_variants,
 	float background_threshold, int use_taq_mama, float *coverage);
 
+/* One amplicon an assay produces on a sequence of the set (AmpliconBounds, assay.h:64-89, plus the stretch
+ * extract_amplicon_seq spells for the multiplex background, pcr_assay.cpp:489-497). */
+typedef struct {
+	uint32_t sequence;               /* AmpliconBounds::index */
+	int32_t  begin, end;             /* first / last base of the amplicon INCLUDING both primers */
+	int32_t  inner_start;            /* first base of the stretch that becomes a multiplex background sequence ... */
+	int32_t  inner_length;           /* ... and its length (non-primer part + MULTIPLEX_AMPLICON_PADDING) */
+	uint32_t orientation;            /* 0: F on the plus strand, 1: R on the plus strand */
+} pcr_amplicon;
+
+/* PCR::collect_unique_amplicons (pcr_assay.cpp:756-813; main.cpp:787,920) for one assay over the word DB of the
+ * last pcr_select_words on `which`: every (plus site, minus site) pair of an active sequence whose oligos match
+ * at threshold^2, do not overlap, span amp_min..amp_max bases and enclose no EOS.  Records sorted by
+ * (orientation, sequence, begin, end).  Returns the number found (may exceed cap; only cap are written) or a
+ * negative error.  The caller cuts the strings from its Sequences, makes them unique (sort + unique, :805-806),
+ * passes them to pcr_multiplex_load and splits the targets at begin, (begin+end)/2 and end (main.cpp:1008-1017). */
+int64_t pcr_collect_amplicons(pcr_ctx *ctx, pcr_set which, const pcr_pair *pair, float threshold, int32_t amp_min, int32_t amp_max,
+	pcr_amplicon *out, uint64_t cap);
+
 /* ---- Random assay sampler (scope row f-2) */
 
 /* The `Options` fields PCR::random_assay reads besides the thermodynamic ones (pcramp.h:21-30). */

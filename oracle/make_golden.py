@@ -384,6 +384,41 @@ def multiplex_optimize_golden(ref):
     return {"cases": cases}
 
 
+def amplicons_golden(ref):
+    """PCR::collect_unique_amplicons: AmpliconBounds and unique amplicon stretches (as nibbles) per assay."""
+    cases = []
+    for ci, opts in enumerate([dict(), dict(target_threshold=0.9), dict(target_threshold=0.85, amp_min=40, amp_max=400)]):
+        o = dict(target_threshold=1.0, amp_min=80, amp_max=200)
+        o.update(opts)
+        rng = random.Random(1618 + ci)
+        seqs = family_targets(rng, 3, 6, 600, div=0.05)
+        q = list(seqs[2])
+        for k in range(100, 500, 23):
+            q[k] = rng.choice("RYKMSWN")
+        seqs[2] = "".join(q)
+        pairs_txt = []
+        while len(pairs_txt) < 6:
+            p = sample_pair(rng, rng.choice(seqs))
+            if p:
+                pairs_txt.append(p)
+        pairs = [(ref.centered_word(f), ref.centered_word(r)) for f, r in pairs_txt]
+        sess = ref.session(**o)
+        for q in seqs:
+            sess.add_target(q, 1.0)
+        splits = [(1, 350), (5, 120), (9, 410)]
+        for i, pos in splits:
+            sess.split(i, pos)
+        sess.set_active(4, False)
+        sess.select(pairs)
+        rows = []
+        for p in pairs:
+            b, a = sess.collect_amplicons(p, o["target_threshold"], o["amp_min"], o["amp_max"])
+            rows.append({"bounds": [list(x) for x in b], "amplicons": ["".join("%x" % v for v in t) for t in a]})
+        cases.append({"options": sess.opts, "seqs": seqs, "splits": splits, "inactive": [4],
+                      "pairs": [hexw(f) + hexw(r) for f, r in pairs], "rows": rows})
+    return {"cases": cases}
+
+
 def main():
     build_reference()
     ref = Reference()
@@ -392,7 +427,7 @@ def main():
     for name, fn in (("words", words_golden), ("pack", pack_golden), ("screen", screen_golden), ("sw", sw_golden),
                      ("thermo", thermo_golden), ("moves", moves_golden), ("sampler", sampler_golden),
                      ("overlap", overlap_golden), ("multiplex", multiplex_golden),
-                     ("multiplex_optimize", multiplex_optimize_golden)):
+                     ("multiplex_optimize", multiplex_optimize_golden), ("amplicons", amplicons_golden)):
         if only and name not in only:
             continue
         with open(os.path.join(OUT, name + ".json"), "w") as f:

@@ -1283,3 +1283,80 @@ extern "C" int orc_multiplex_coverage(orc_session *s, const uint64_t base[4], in
 	}
 	return 0;
 }
+
+// ------------------------------------------------------------------------------------ amplicons of an accepted assay (row f-3)
+namespace {
+
+const char BASE_LETTER[17] = "-ACMGRSVTWYHKDBN";                                  // bits_to_base, base_table.h:78-123 (for the sort order of the amplicon strings)
+
+// PCR::extract_amplicon_seq, pcr_assay.cpp:443-542
+void extract_amplicon_seq(std::vector<std::string> &amps, std::vector<unsigned> *bounds, const std::vector<OligoMatch> &m,
+	uint8_t plus_o, uint8_t minus_o, const W &plus_w, const W &minus_w, const orc_session &s, int amp_min, int amp_max)
+{
+	const int PAD = 4;                                                            // MULTIPLEX_AMPLICON_PADDING, pcramp.h:57
+	const int ps = plus_w.start(), pe = plus_w.stop(), ms = minus_w.start(), me = minus_w.stop();
+	for(size_t p = 0;p < m.size();++p){
+		if(m[p].o != plus_o) continue;
+		for(size_t q = p;q < m.size();++q){
+			if(m[p].index != m[q].index) break;
+			if(m[q].o != minus_o) continue;
+			if(loc3(m[p], ps, pe) >= loc5(m[q], ms, me)) continue;                // :468-471
+			const int amp_len = loc3(m[q], ms, me) - loc5(m[p], ps, pe) + 1;
+			if(amp_len < amp_min) continue;
+			if(amp_len > amp_max) break;
+			const unsigned amp_start = (unsigned)(loc3(m[p], ps, pe) + 1 - PAD);  // :489-490 (unsigned there)
+			const unsigned np_len = (unsigned)loc5(m[q], ms, me) - amp_start + 2*PAD;   // :492-494
+			const Seq &t = s.seq[m[p].index];
+			std::string a(np_len, '?');
+			bool valid = true;
+			for(unsigned i = 0;i < np_len;++i){
+				const uint64_t pos = (uint64_t)amp_start + i;
+				const unsigned b = (pos < t.len) ? t.at(pos) : (unsigned)EOS;         // past the end: undefined there; an EOS here
+				if(b == EOS){ valid = false; break; }
+				a[i] = BASE_LETTER[b];
+			}
+			if(!valid) break;                                                     // :517-521
+			amps.push_back(a);
+			if(bounds){ bounds->push_back(m[p].index); bounds->push_back((unsigned)loc5(m[p], ps, pe)); bounds->push_back((unsigned)loc3(m[q], ms, me)); }
+		}
+	}
+}
+
+} // namespace
+
+extern "C" long orc_session_collect_amplicons(orc_session *s, const uint64_t pair[4], float threshold, int amp_min, int amp_max,
+	unsigned *bounds_out, long cap_bounds, unsigned char *amp_codes_out, long cap_codes, unsigned *amp_len_out, long cap_amp,
+	long *n_amp_out)
+{
+	const W F = load_word(pair), R = load_word(pair + 2);
+	std::vector<uint32_t> fm, rm;
+	match_words(fm, F, s->keys, threshold*threshold);                             // :775-776
+	match_words(rm, R, s->keys, threshold*threshold);
+	std::vector<std::string> amps;
+	std::vector<unsigned> bounds;
+	std::vector<OligoMatch> om;
+	find_oligo_match(om, fm, 0, PLUS, *s);
+	find_oligo_match(om, rm, 1, MINUS, *s);
+	std::stable_sort(om.begin(), om.end(), om_less);
+	extract_amplicon_seq(amps, &bounds, om, 0, 1, F, R, *s, amp_min, amp_max);
+	om.clear();
+	find_oligo_match(om, fm, 0, MINUS, *s);
+	find_oligo_match(om, rm, 1, PLUS, *s);
+	std::stable_sort(om.begin(), om.end(), om_less);
+	extract_amplicon_seq(amps, &bounds, om, 1, 0, R, F, *s, amp_min, amp_max);
+	std::sort(amps.begin(), amps.end());                                          // :805-806
+	amps.erase(std::unique(amps.begin(), amps.end()), amps.end());
+	long used = 0, na = 0;
+	for(const std::string &a : amps){
+		if(na < cap_amp) amp_len_out[na] = (unsigned)a.size();
+		for(char c : a){
+			if(used < cap_codes) amp_codes_out[used] = (unsigned char)(strchr(BASE_LETTER, c) - BASE_LETTER);
+			++used;
+		}
+		++na;
+	}
+	if(n_amp_out) *n_amp_out = na;
+	const long nb = (long)(bounds.size()/3);
+	for(long i = 0;i < nb && i < cap_bounds;++i){ bounds_out[3*i] = bounds[3*i]; bounds_out[3*i + 1] = bounds[3*i + 1]; bounds_out[3*i + 2] = bounds[3*i + 2]; }
+	return (used > cap_codes || na > cap_amp) ? -3 : nb;
+}

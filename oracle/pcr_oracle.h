@@ -107,6 +107,14 @@ int orc_optimization_move(orc_session *t, orc_session *b, const uint64_t pair[4]
 int orc_optimize(orc_session *t, orc_session *b, uint64_t pair_inout[4], const int *moves, int n_moves,
 	const orc_move_options *mo, float out_score[3], int *iterations_out);
 
+// PCR::collect_unique_amplicons (pcr_assay.cpp:756-813) over the session's word DB (orc_session_select first):
+// bounds_out = n x {sequence, begin, end} in the reference's discovery order (AmpliconBounds, first/last base
+// incl. primers); amp_codes_out = the unique amplicon stretches (non-primer part + padding, pcr_assay.cpp:489-497)
+// as nibbles back to back, amp_len_out[k] their lengths, in the reference's sorted order.  Returns the number of
+// bounds (may exceed cap_bounds), *n_amp_out = number of unique amplicons; <0 on error.
+long orc_session_collect_amplicons(orc_session *s, const uint64_t pair[4], float threshold, int amp_min, int amp_max,
+	unsigned *bounds_out, long cap_bounds, unsigned char *amp_codes_out, long cap_codes, unsigned *amp_len_out, long cap_amp,
+	long *n_amp_out);
 // Multiplex background coverage (pcr_assay.cpp:71-102, :304-336) with the session's sequences as the accepted
 // amplicons: DB = pack of every sequence (session pack_max_degen, no G+C filter, min_primer; main.cpp:989-1001),
 // candidates of `base`, then per trial word of the oligo on `side` update_identity + the distinct-key count.

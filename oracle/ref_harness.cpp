@@ -867,6 +867,35 @@ float ref_oligo_overlap(const uint64_t assay[4], const uint64_t *pool, unsigned 
 	return p.compute_oligo_overlap(q);
 }
 
+// PCR::collect_unique_amplicons (pcr_assay.cpp:756-813) over the session's DB: bounds in discovery order, the
+// unique amplicon Sequences as nibbles back to back.
+long ref_session_collect_amplicons(RefSession *s, const uint64_t pair[4], float threshold, int amp_min, int amp_max,
+	unsigned *bounds_out, long cap_bounds, unsigned char *amp_codes_out, long cap_codes, unsigned *amp_len_out, long cap_amp,
+	long *n_amp_out)
+{
+	try{
+		PCR p;
+		p.oligo( FORWARD, word_from(pair) );
+		p.oligo( REVERSE, word_from(pair + 2) );
+		deque<AmpliconBounds> bounds;
+		const deque<Sequence> amps = p.collect_unique_amplicons(s->target_keys, s->target_db, s->target_seq, threshold,
+			make_pair(amp_min, amp_max), &bounds);
+		long used = 0, na = 0;
+		for(deque<Sequence>::const_iterator a = amps.begin();a != amps.end();++a, ++na){
+			if(na < cap_amp) amp_len_out[na] = (unsigned)a->length();
+			for(size_t i = 0;i < a->length();++i, ++used){ if(used < cap_codes) amp_codes_out[used] = (*a)[i]; }
+		}
+		if(n_amp_out) *n_amp_out = na;
+		long nb = 0;
+		for(deque<AmpliconBounds>::const_iterator b = bounds.begin();b != bounds.end();++b, ++nb){
+			if(nb < cap_bounds){ bounds_out[3*nb] = b->index; bounds_out[3*nb + 1] = b->begin; bounds_out[3*nb + 2] = b->end; }
+		}
+		return (used > cap_codes || na > cap_amp) ? -3 : nb;
+	}
+	catch(const char *e){ s->last_error = e; return -1; }
+	catch(...){ s->last_error = "unknown"; return -2; }
+}
+
 // The multiplex background coverage as optimize() / the moves evaluate it (optimize.cpp:82-92,
 // optimize_pcr.cpp:111-127): DB = pack of the session's sequences the way main.cpp:989-1001 packs accepted
 // amplicons, candidates of the base assay, identity map of the edited oligo recomputed per trial word.

@@ -55,6 +55,11 @@ class ThermoArgs(C.Structure):
                 ("max_hairpin", C.c_float), ("max_dimer", C.c_float)]
 
 
+class Amplicon(C.Structure):
+    _fields_ = [("sequence", C.c_uint32), ("begin", C.c_int32), ("end", C.c_int32), ("inner_start", C.c_int32),
+                ("inner_length", C.c_int32), ("orientation", C.c_uint32)]
+
+
 class SamplerArgs(C.Structure):
     _fields_ = [("primer_min", C.c_int32), ("primer_max", C.c_int32), ("amp_min", C.c_int32), ("amp_max", C.c_int32),
                 ("max_degen", C.c_double)]
@@ -91,7 +96,7 @@ ABI_SYMBOLS = [
     "pcr_sw_align_words", "pcr_background_match", "pcr_multiplex_match",
     "pcr_thermo", "pcr_dimer", "pcr_multiplex_compatible",
     "pcr_random_assays", "pcr_host_rand_r", "pcr_host_max_overlap", "pcr_host_oligo_overlap", "pcr_host_pool_overlaps",
-    "pcr_multiplex_load", "pcr_multiplex_coverage",
+    "pcr_multiplex_load", "pcr_multiplex_coverage", "pcr_collect_amplicons",
 ]
 
 
@@ -146,6 +151,8 @@ def load_library():
     L.pcr_multiplex_compatible.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(ThermoArgs), C.c_void_p]
     L.pcr_random_assays.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(SamplerArgs),
                                     C.POINTER(ThermoArgs), C.c_void_p, C.c_void_p]
+    L.pcr_collect_amplicons.restype = C.c_int64
+    L.pcr_collect_amplicons.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_int32, C.c_int32, C.c_void_p, C.c_uint64]
     L.pcr_multiplex_load.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
     L.pcr_multiplex_coverage.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_float, C.c_int, C.c_void_p]
     L.pcr_host_pool_overlaps.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
@@ -490,6 +497,20 @@ class Screener:
             return np.frombuffer(out, dtype=np.uint32).reshape(-1, 8)[:len(oligos), 0] != 0
         return [dict(valid=bool(r.valid), n=r.n_expansions, tm=np.float32(r.tm), dH=np.float32(r.dH), dS=np.float32(r.dS),
                      hairpin_tm=np.float32(r.hairpin_tm), homodimer_tm=np.float32(r.homodimer_tm)) for r in out[:len(oligos)]]
+
+    def collect_amplicons(self, pair, threshold=1.0, amp_min=80, amp_max=200, which=TARGET, cap=4096):
+        """PCR::collect_unique_amplicons: -> [dict(sequence, begin, end, inner_start, inner_length, orientation)]
+        sorted by (orientation, sequence, begin, end)."""
+        a = W.pairs_array([pair])
+        while True:
+            buf = (Amplicon * cap)()
+            n = self.L.pcr_collect_amplicons(self.h, which, a.ctypes.data, float(threshold), int(amp_min), int(amp_max), buf, cap)
+            if n < 0:
+                raise PcrError(_err(self.L))
+            if n <= cap:
+                return [dict(sequence=r.sequence, begin=r.begin, end=r.end, inner_start=r.inner_start,
+                             inner_length=r.inner_length, orientation=r.orientation) for r in buf[:n]]
+            cap = int(n)
 
     def multiplex_load(self, seqs, min_oligo_length=18):
         """The multiplex background keys (main.cpp:989-1001) from amplicon texts -> number of unique keys."""

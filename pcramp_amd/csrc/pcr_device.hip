@@ -601,6 +601,7 @@ struct pcr_ctx {
 	DevBuf<AmpRec> amp_recs; DevBuf<BgPairDev> bg_pairs;
 	DevBuf<thermo::Job> th_jobs; DevBuf<thermo::JobOut> th_out; DevBuf<int> th_dg, th_scratch_i; DevBuf<unsigned short> th_scratch_s;
 	float th_dg_salt = -1.0f;   // salt the table in th_dg was built for
+	DevBuf<pcr_amplicon> mx_amp;   // pcr_collect_amplicons records
 	DevBuf<Planes> mx_keys; uint32_t mx_n_keys = 0; DevBuf<uint32_t> mx_count;   // multiplex background: unique words of the accepted amplicons (pcr_multiplex.inc)
 	size_t amp_cap = size_t(1) << 20;
 	uint32_t n_cu = 256;        // compute units of the device (hipDeviceProp)
@@ -1115,7 +1116,7 @@ void pcr_destroy(pcr_ctx *ctx)
 	if(ctx->mail) (void)hipHostFree(ctx->mail);
 	if(ctx->ret_host) (void)hipHostFree(ctx->ret_host);
 	if(ctx->ret_flag) (void)hipHostFree(ctx->ret_flag);
-	ctx->oligos.release(); ctx->sw_jobs.release(); ctx->sw_out.release(); ctx->sw_q.release(); ctx->sw_qlen.release(); ctx->sw_t.release(); ctx->entry_codes.release(); ctx->entry_lens.release(); ctx->amp_recs.release(); ctx->bg_pairs.release(); ctx->th_jobs.release(); ctx->th_out.release(); ctx->th_dg.release(); ctx->th_scratch_i.release(); ctx->th_scratch_s.release(); ctx->mx_keys.release(); ctx->mx_count.release();
+	ctx->oligos.release(); ctx->sw_jobs.release(); ctx->sw_out.release(); ctx->sw_q.release(); ctx->sw_qlen.release(); ctx->sw_t.release(); ctx->entry_codes.release(); ctx->entry_lens.release(); ctx->amp_recs.release(); ctx->bg_pairs.release(); ctx->th_jobs.release(); ctx->th_out.release(); ctx->th_dg.release(); ctx->th_scratch_i.release(); ctx->th_scratch_s.release(); ctx->mx_keys.release(); ctx->mx_count.release(); ctx->mx_amp.release();
 	if(ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 }

@@ -505,6 +505,29 @@ class Session:
             raise RuntimeError(self.f("session_error")(self.h))
         return cov[:len(variants)]
 
+    def collect_amplicons(self, pair, threshold=1.0, amp_min=80, amp_max=200):
+        """PCR::collect_unique_amplicons -> (bounds [(seq, begin, end)] in discovery order,
+        unique amplicons as tuples of nibbles in the reference's sorted order)."""
+        a = pairs_array([pair])
+        cap_b, cap_c, cap_a = 1 << 16, 1 << 22, 1 << 16
+        bounds = np.zeros(3 * cap_b, dtype=np.uint32)
+        codes = np.zeros(cap_c, dtype=np.uint8)
+        lens = np.zeros(cap_a, dtype=np.uint32)
+        na = C.c_long(0)
+        fn = self.f("session_collect_amplicons")
+        fn.restype = C.c_long
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_void_p, C.c_long,
+                       C.c_void_p, C.c_long, C.POINTER(C.c_long)]
+        nb = fn(self.h, a.ctypes.data, threshold, amp_min, amp_max, bounds.ctypes.data, cap_b, codes.ctypes.data, cap_c,
+                lens.ctypes.data, cap_a, C.byref(na))
+        if nb < 0:
+            raise RuntimeError("collect_amplicons failed: %d" % nb)
+        amps, off = [], 0
+        for k in range(na.value):
+            amps.append(tuple(int(x) for x in codes[off:off + lens[k]]))
+            off += int(lens[k])
+        return [tuple(int(x) for x in bounds[3 * i:3 * i + 3]) for i in range(nb)], amps
+
     def multiplex_coverage(self, base_pair, side, variants, background_threshold=0.8, use_taq_mama=0):
         """The session's sequences as accepted amplicons -> (float32[n_variants], number of keys)."""
         a = pairs_array([base_pair])

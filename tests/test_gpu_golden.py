@@ -182,3 +182,32 @@ def test_multiplex_optimize_golden(ci):
             assert tuple(float(x) for x in s) == tuple(float(np.float32(x)) for x in sc), (pi, use_pool)
     finally:
         d.close()
+
+
+@pytest.mark.parametrize("ci", range(3))
+def test_collect_amplicons_golden(ci):
+    """pcr_collect_amplicons against tests/golden/amplicons.json (the reference's collect_unique_amplicons)."""
+    from pcramp_amd import words as W
+    with open(os.path.join(G, "amplicons.json")) as f:
+        c = json.load(f)["cases"][ci]
+    o = c["options"]
+    hw = lambda h: (int(h[0], 16), int(h[1], 16))
+    d = api.Screener(0)
+    try:
+        seqs = list(c["seqs"])
+        d.load_texts(seqs, [1.0] * len(seqs))
+        for i, pos in c["splits"]:
+            d.split(i, pos)
+            seqs[i] = seqs[i][:pos] + "-" + seqs[i][pos + 1:]
+        d.set_active([i not in c["inactive"] for i in range(len(seqs))])
+        pairs = [(hw(p[:2]), hw(p[2:])) for p in c["pairs"]]
+        thr = float(np.float32(o["target_threshold"]) * np.float32(o["search_multiplier"]))
+        d.select_words(pairs, thr, o["min_primer"])
+        codes = [W.codes_from_text(s) for s in seqs]
+        for p, row in zip(pairs, c["rows"]):
+            rec = d.collect_amplicons(p, o["target_threshold"], o["amp_min"], o["amp_max"])
+            assert sorted([r["sequence"], r["begin"], r["end"]] for r in rec) == sorted(row["bounds"])
+            got = {"".join("%x" % int(v) for v in codes[r["sequence"]][r["inner_start"]:r["inner_start"] + r["inner_length"]]) for r in rec}
+            assert got == set(row["amplicons"])
+    finally:
+        d.close()

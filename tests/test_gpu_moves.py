@@ -315,3 +315,56 @@ def test_optimization_move_multiplex_matches_oracle(oracle, case):
         assert found > 20
     finally:
         d.close()
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(target_threshold=0.9), dict(target_threshold=0.85, amp_min=40, amp_max=400)])
+def test_collect_amplicons_matches_oracle(oracle, opts):
+    """pcr_collect_amplicons (PCR::collect_unique_amplicons, pcr_assay.cpp:756-813): the AmpliconBounds and the
+    unique amplicon stretches of an assay, against the oracle (== the compiled reference), with EOS splits,
+    IUPAC bases and an inactive sequence; then the round trip the multiplex loop makes with them: load the
+    amplicons as the multiplex background, split the targets at begin / middle / end."""
+    o = dict(target_threshold=1.0, amp_min=80, amp_max=200)
+    o.update(opts)
+    rng = random.Random(31415 + len(opts))
+    seqs = family_targets(rng, 3, 7, 700, div=0.05)
+    q = list(seqs[2])
+    for k in range(100, 600, 23):
+        q[k] = rng.choice("RYKMSWN")
+    seqs[2] = "".join(q)
+    pairs_txt = []
+    while len(pairs_txt) < 8:
+        p = sample_pair(rng, rng.choice(seqs))
+        if p:
+            pairs_txt.append(p)
+    pairs = [(oracle.centered_word(f), oracle.centered_word(r)) for f, r in pairs_txt]
+    so = oracle.session(**o)
+    for s in seqs:
+        so.add_target(s, 1.0)
+    d = api.Screener(0)
+    try:
+        d.load_texts(seqs, [1.0] * len(seqs))
+        for i, pos in ((1, 350), (5, 120), (9, 500)):
+            so.split(i, pos)
+            d.split(i, pos)
+            seqs[i] = seqs[i][:pos] + "-" + seqs[i][pos + 1:]
+        so.set_active(4, False)
+        d.set_active([i != 4 for i in range(len(seqs))])
+        so.select(pairs)
+        d.select_words(pairs, float(np.float32(o["target_threshold"]) * np.float32(0.9)), 18)
+        codes = [W.codes_from_text(s) for s in seqs]
+        n_b = n_a = 0
+        for p in pairs:
+            bo, ao = so.collect_amplicons(p, o["target_threshold"], o["amp_min"], o["amp_max"])
+            rec = d.collect_amplicons(p, o["target_threshold"], o["amp_min"], o["amp_max"], cap=2)   # forces the grow-and-retry path
+            assert sorted((r["sequence"], r["begin"], r["end"]) for r in rec) == sorted(bo)
+            got = sorted({tuple(int(x) for x in codes[r["sequence"]][r["inner_start"]:r["inner_start"] + r["inner_length"]]) for r in rec})
+            assert got == sorted(set(ao))
+            assert all(0 not in a for a in got)
+            n_b += len(bo)
+            n_a += len(ao)
+            if rec:                                                    # main.cpp:989-1017 with these amplicons
+                texts = ["".join(W.text_from_codes(np.array(a, np.uint8))) for a in got]
+                assert d.multiplex_load(texts, 18) > 0
+        assert n_b >= 5 and n_a >= 3, (n_b, n_a)
+    finally:
+        d.close()

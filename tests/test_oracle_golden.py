@@ -204,3 +204,22 @@ def test_multiplex_optimize(oracle, ci):
         got = optimize_multiplex(oracle, ts, bs, ams, pool if use_pool else [], cands[pi], **c["move_options"])
         assert got[0] == pw(bp), (pi, use_pool)
         assert got[1] == tuple(float(np.float32(x)) for x in sc), (pi, use_pool)
+
+
+@pytest.mark.parametrize("ci", range(3))
+def test_collect_amplicons(oracle, ci):
+    c = load("amplicons")["cases"][ci]
+    o = c["options"]
+    sess = oracle.session(**o)
+    for q in c["seqs"]:
+        sess.add_target(q, 1.0)
+    for i, pos in c["splits"]:
+        sess.split(i, pos)
+    for i in c["inactive"]:
+        sess.set_active(i, False)
+    pairs = [(_hw(p[:2]), _hw(p[2:])) for p in c["pairs"]]
+    sess.select(pairs)
+    for p, row in zip(pairs, c["rows"]):
+        b, a = sess.collect_amplicons(p, o["target_threshold"], o["amp_min"], o["amp_max"])
+        assert [list(x) for x in b] == row["bounds"]
+        assert ["".join("%x" % v for v in t) for t in a] == row["amplicons"]

@@ -606,3 +606,36 @@ def test_optimization_move_multiplex(oracle, reference, case):
                 assert ro == rr, (p, side, move, ro, rr)
                 found += ro[0] != (0, 0)
     assert found > 20
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(target_threshold=0.9), dict(target_threshold=0.85, amp_min=40, amp_max=400)])
+def test_collect_unique_amplicons(oracle, reference, opts):
+    """PCR::collect_unique_amplicons (pcr_assay.cpp:756-813): AmpliconBounds in discovery order and the unique
+    amplicon stretches, with EOS splits, IUPAC bases and inactive sequences in the targets."""
+    o = dict(target_threshold=1.0, amp_min=80, amp_max=200)
+    o.update(opts)
+    rng = random.Random(2718 + len(opts))
+    seqs = family_targets(rng, 3, 7, 700, div=0.05)
+    q = list(seqs[2])
+    for k in range(100, 600, 23):
+        q[k] = rng.choice("RYKMSWN")
+    seqs[2] = "".join(q)
+    pairs_txt = []
+    while len(pairs_txt) < 8:
+        p = sample_pair(rng, rng.choice(seqs))
+        if p:
+            pairs_txt.append(p)
+    pairs = [(reference.centered_word(f), reference.centered_word(r)) for f, r in pairs_txt]
+    so, sr = _sessions(oracle, reference, seqs, None, **o)
+    for i, pos in ((1, 350), (5, 120), (9, 500)):
+        so.split(i, pos); sr.split(i, pos)
+    so.set_active(4, False); sr.set_active(4, False)
+    assert so.select(pairs) == sr.select(pairs)
+    n_b = n_a = 0
+    for p in pairs:
+        bo, ao = so.collect_amplicons(p, o["target_threshold"], o["amp_min"], o["amp_max"])
+        br, ar = sr.collect_amplicons(p, o["target_threshold"], o["amp_min"], o["amp_max"])
+        assert bo == br
+        assert ao == ar
+        n_b += len(bo); n_a += len(ao)
+    assert n_b >= 5 and n_a >= 3, (n_b, n_a)
