@@ -6,8 +6,9 @@ out, so PCIe and launch overhead are included -- end-to-end per call, not kernel
   * thermodynamics, small batch (the latency the local search and the sampler see): seconds per call of 64 oligos
   * local-search move evaluation (pcr_move_coverage): trial words/s at C2 scale
   * the optimize() loop of the local search (pcramp_amd.moves.optimize) on C2 targets + 2 000 backgrounds: seconds per
-    assay, with the CPU oracle's loop beside it on the same sessions
-  * random assay sampler (pcr_random_assays): trials/s on the C2 targets, with the CPU oracle beside it
+    assay
+  * random assay sampler (pcr_random_assays): trials/s on the C2 targets (the CPU oracle's time for the same 1 000
+    trials is printed by tests/test_gpu_sampler.py::test_sampler_at_c2_scale -- checkers live under tests/)
 Prints one JSON object.  python profiles/bench_kernels.py"""
 import json
 import os
@@ -94,20 +95,6 @@ def main():
     dt = time.perf_counter() - t0
     out["sampler"] = {"trials": 1000, "seconds": dt, "trials_per_s": 1000 / dt,
                       "mean_attempts": sum(i["assay_iterations"] for i in info) / 1000.0}
-    try:                                                               # CPU oracle beside it (checker, not product)
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        from oracle_lib import Oracle, random_assays
-        orc = Oracle()
-        so = orc.session()
-        for i in range(wl["T"]):
-            lo = int(wl["byte_offsets"][i])
-            so.add_target_packed(wl["packed"][lo:lo + (int(wl["lengths"][i]) + 1) // 2], int(wl["lengths"][i]))
-        t0 = time.perf_counter()
-        want, _ = random_assays(orc, so, 7, 1000)
-        out["sampler"]["cpu_oracle_seconds"] = time.perf_counter() - t0
-        out["sampler"]["matches_oracle"] = bool(want == pairs)
-    except Exception as e:                                             # noqa: BLE001
-        out["sampler"]["cpu_oracle_error"] = str(e)
     scr.close()
     print(json.dumps(out))
 

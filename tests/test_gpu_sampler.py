@@ -96,3 +96,31 @@ def test_random_assay_errors():
             d.random_assays(1, 1)
     finally:
         d.close()
+
+
+def test_sampler_at_c2_scale(oracle, capsys):
+    """1 000 trials on the 10 000 x 10 kb bench targets: identical to the oracle; both times are printed
+    (`pytest -s`) -- the figures DESIGN.md quotes."""
+    import time
+    from oracle_lib import random_assays
+    from pcramp_amd import synth
+    wl = synth.workload("C2", 0, 1.0)
+    so = oracle.session()
+    for i in range(wl["T"]):
+        lo = int(wl["byte_offsets"][i])
+        so.add_target_packed(wl["packed"][lo:lo + (int(wl["lengths"][i]) + 1) // 2], int(wl["lengths"][i]))
+    d = api.Screener(0)
+    try:
+        d.load_sequences(wl["packed"], wl["byte_offsets"], wl["lengths"])
+        d.random_assays(1, 20)
+        t0 = time.perf_counter()
+        got, s, _ = d.random_assays(7, 1000)
+        t_dev = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        want, after = random_assays(oracle, so, 7, 1000)
+        t_cpu = time.perf_counter() - t0
+        assert got == want and s == after
+        with capsys.disabled():
+            print("\n[sampler, C2 targets, 1000 trials] device path %.3f s, CPU oracle %.3f s" % (t_dev, t_cpu))
+    finally:
+        d.close()
