@@ -625,6 +625,7 @@ struct pcr_ctx {
 	// copies them into a host-mapped buffer and raises a flag the host spins on (no copy-engine packets, no
 	// interrupt wake-up; three pageable hipMemcpyAsync + a stream sync cost ~1.8 ms per call instead)
 	uint8_t *ret_host = nullptr, *ret_dev = nullptr; size_t ret_cap = 0;
+	uint8_t *in_host = nullptr, *in_dev = nullptr; size_t in_cap = 0;   // the way in for small synchronous calls: a mapped buffer the kernel reads directly (the call waits for its results, so one buffer is enough)
 	uint32_t *ret_flag = nullptr, *ret_flag_dev = nullptr; uint32_t ret_seq = 0;
 	// passes enqueued by pcr_screen_device whose counters have not been looked at yet (pcr_synchronize / any
 	// other entry point drains them; a bucket overflow found then replays the passes synchronously)
@@ -895,6 +896,23 @@ int return_to_host(pcr_ctx *ctx, const void *s0, size_t b0, const void *s1, size
 	return PCR_OK;
 }
 
+// Small inputs of a synchronous call: copied into a host-mapped buffer that the kernel reads in place (a pageable
+// hipMemcpyAsync costs ~20 us).  Valid until the next call; the caller waits for its results before returning.
+int mapped_input(pcr_ctx *ctx, const void *src, size_t bytes, const void **dev_out)
+{
+	if(bytes > ctx->in_cap){
+		HIP_TRY(hipStreamSynchronize(ctx->stream));
+		if(ctx->in_host){ (void)hipHostFree(ctx->in_host); ctx->in_host = nullptr; ctx->in_cap = 0; }
+		const size_t want = std::max<size_t>(bytes*2, 1 << 18);
+		HIP_TRY(hipHostMalloc((void **)&ctx->in_host, want, hipHostMallocMapped | hipHostMallocCoherent));
+		HIP_TRY(hipHostGetDevicePointer((void **)&ctx->in_dev, ctx->in_host, 0));
+		ctx->in_cap = want;
+	}
+	memcpy(ctx->in_host, src, bytes);
+	*dev_out = ctx->in_dev;
+	return PCR_OK;
+}
+
 // pcr_screen_device: the amplicon screen's oligo table and the clearing of its result bitsets ride in the
 // select pass's staging launch, and the pass's counters are published by k_match instead of k_publish.
 struct FusedAmp {
@@ -1115,6 +1133,7 @@ void pcr_destroy(pcr_ctx *ctx)
 	for(auto &sl : ctx->stage){ if(sl.host) (void)hipHostFree(sl.host); if(sl.done) (void)hipEventDestroy(sl.done); }
 	if(ctx->mail) (void)hipHostFree(ctx->mail);
 	if(ctx->ret_host) (void)hipHostFree(ctx->ret_host);
+	if(ctx->in_host) (void)hipHostFree(ctx->in_host);
 	if(ctx->ret_flag) (void)hipHostFree(ctx->ret_flag);
 	ctx->oligos.release(); ctx->sw_jobs.release(); ctx->sw_out.release(); ctx->sw_q.release(); ctx->sw_qlen.release(); ctx->sw_t.release(); ctx->entry_codes.release(); ctx->entry_lens.release(); ctx->amp_recs.release(); ctx->bg_pairs.release(); ctx->th_jobs.release(); ctx->th_out.release(); ctx->th_dg.release(); ctx->th_scratch_i.release(); ctx->th_scratch_s.release(); ctx->mx_keys.release(); ctx->mx_count.release(); ctx->mx_amp.release();
 	if(ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
