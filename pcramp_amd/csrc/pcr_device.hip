@@ -1856,9 +1856,14 @@ int pcr_move_coverage(pcr_ctx *ctx, pcr_set which, const pcr_pair *base, int sid
 	hipLaunchKernelGGL(k_match_few, dim3((n_db + 255)/256), dim3(256), 0, ctx->stream, S.db.p, n_db, S.db_cap, S.touched.p, S.d_seg_hi, d_ol, 2u,
 		ctx->mask.p, ctx->status.p);
 	HIP_TRY(hipGetLastError());
-	hipLaunchKernelGGL(k_pair_moves, dim3((n_db + 127)/128), dim3(128), 0, ctx->stream, S.db.p, n_db, S.db_cap, S.touched.p, S.d_seg_hi, ctx->mask.p,
-		d_ol, d_ol + 2, n_variants, side, S.planes.p, S.d_blk_off.p, S.d_len.p, S.d_active.p, S.d_has_eos.p, args->amp_min, args->amp_max,
-		args->ident_threshold, args->use_taq_mama, ctx->bits_fr.p, ctx->bits_rf.p, words, ctx->status.p);
+	if(S.db_cap >= 256 && S.db_cap <= PMS_MAX)                                    // big buckets: a workgroup per sequence over a compact partner list
+		hipLaunchKernelGGL(k_pair_moves_seq, dim3(S.n_touched), dim3(PMS_THREADS), 0, ctx->stream, S.db.p, S.db_cap, S.touched.p, S.d_seg_hi, ctx->mask.p,
+			d_ol, d_ol + 2, n_variants, side, S.planes.p, S.d_blk_off.p, S.d_len.p, S.d_active.p, S.d_has_eos.p, args->amp_min, args->amp_max,
+			args->ident_threshold, args->use_taq_mama, ctx->bits_fr.p, ctx->bits_rf.p, words, ctx->status.p);
+	else
+		hipLaunchKernelGGL(k_pair_moves, dim3((n_db + 127)/128), dim3(128), 0, ctx->stream, S.db.p, n_db, S.db_cap, S.touched.p, S.d_seg_hi, ctx->mask.p,
+			d_ol, d_ol + 2, n_variants, side, S.planes.p, S.d_blk_off.p, S.d_len.p, S.d_active.p, S.d_has_eos.p, args->amp_min, args->amp_max,
+			args->ident_threshold, args->use_taq_mama, ctx->bits_fr.p, ctx->bits_rf.p, words, ctx->status.p);
 	HIP_TRY(hipGetLastError());
 	const uint8_t *back[3];
 	if((rc = return_to_host(ctx, ctx->bits_fr.p, total*sizeof(uint64_t), ctx->bits_rf.p, total*sizeof(uint64_t), ctx->status.p, sizeof(uint32_t), back)) != PCR_OK) return rc;

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from pcramp_amd import api, words as W
-from testdata import family_targets, sample_pair, move_variants
+from testdata import family_targets, sample_pair, move_variants, rand_seq, mutate, revcomp
 
 pytestmark = pytest.mark.gpu
 
@@ -366,5 +366,48 @@ def test_collect_amplicons_matches_oracle(oracle, opts):
                 texts = ["".join(W.text_from_codes(np.array(a, np.uint8))) for a in got]
                 assert d.multiplex_load(texts, 18) > 0
         assert n_b >= 5 and n_a >= 3, (n_b, n_a)
+    finally:
+        d.close()
+
+
+def test_move_coverage_big_buckets(oracle):
+    """Hundreds of DB entries per sequence (low select threshold, every slot shift, repetitive sequences): the
+    bucket capacity grows past 256 slots and pcr_move_coverage takes its workgroup-per-sequence form
+    (k_pair_moves_seq: compact partner list in LDS).  Wide amplicon range, EOS splits, both sides."""
+    o = dict(target_threshold=0.8, search_multiplier=0.8, amp_min=0, amp_max=1500, use_taq_mama=1,
+             pack_max_degen=256, pack_min_gc=0.0, pack_max_gc=1.0, min_primer=16, optimize_5=1, optimize_3=1)
+    rng = random.Random(8086)
+    unit = rand_seq(rng, 60)
+    seqs = []
+    for i in range(10):
+        s = "".join(mutate(rng, unit, 0.08) for _ in range(40))       # 2 400 bases of diverged repeats
+        seqs.append(s)
+    f, r = unit[5:27], revcomp(unit[30:52])
+    pairs = [(oracle.centered_word(f), oracle.centered_word(r)), (oracle.centered_word(mutate(rng, f, 0.1)), oracle.centered_word(r))]
+    so = oracle.session(**o)
+    for s in seqs:
+        so.add_target(s, 1.0)
+    d = api.Screener(0)
+    try:
+        d.load_texts(seqs, [1.0] * len(seqs))
+        for i, pos in ((2, 700), (2, 1500), (7, 300)):
+            so.split(i, pos)
+            d.split(i, pos)
+        thr = float(np.float32(o["target_threshold"]) * np.float32(o["search_multiplier"]))
+        n = so.select(pairs)
+        assert d.select_words(pairs, thr, o["min_primer"], True, True) == n
+        assert n > 256 * len(seqs) // 2                                # enough entries per sequence for big buckets
+        for p in pairs:
+            for side in (0, 1):
+                var = [p[side]]
+                for kind in ("inc", "trim5", "trim3", "grow5", "grow3"):
+                    var += move_variants(W, p[side], kind)
+                co, oo = so.move_coverage(p, side, var, orient=True)
+                cd, fr, rf = d.move_coverage(p, side, var, o["target_threshold"], o["search_multiplier"], o["amp_min"],
+                                             o["amp_max"], True)
+                assert np.array_equal(cd, co)
+                assert np.array_equal(fr, (oo & 1) != 0)
+                assert np.array_equal(rf, (oo & 2) != 0)
+                assert np.count_nonzero(co) > 0
     finally:
         d.close()
