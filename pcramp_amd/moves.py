@@ -194,7 +194,8 @@ def _decide_move(rows, score_threshold, move=None, partial=None):
 
 
 def optimize(scr, pair, move_list=DEFAULT_MOVES, **opts):
-    """optimize() (optimize.cpp:14-207), non-multiplex: greedy local search over both oligos.
+    """optimize() (optimize.cpp:14-207): greedy local search over both oligos; `pool=[...]` (the assays designed so
+    far; may be empty) switches opt.use_multiplex on.
 
     Per iteration: score of the current assay (collect + update + compute coverage, :61-79), every move of
     every oligo against the running best (`local_score` doubles as the moves' score threshold, :126-130; ties
