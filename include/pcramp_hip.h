@@ -194,12 +194,19 @@ typedef struct {
 	float background_threshold;  /* the final score test (background_match.cpp:116) */
 	int32_t amp_min, amp_max;    /* opt.background_amplicon_range */
 	int32_t use_taq_mama;
+	int32_t evaluate_all_amplicons;  /* 0 (default): reference-identical -- see below; 1: every candidate amplicon counts */
 } pcr_background_args;
 
 /* PCR::find_background_match (background_match.cpp:7-166) for a batch of pairs against the set's
  * current word DB: candidate amplicons -> 4 alignments each -> normalised score product ->
- * bits[pair][seq].  Every candidate amplicon is evaluated (the reference's `(i+1) >= num_seq`
- * loop test, :122, skips some and can read out of bounds). */
+ * bits[pair][seq].
+ * The reference aligns its candidate amplicons two per SeqOverlap call (:66-75) and tests
+ * `(i + 1) >= num_seq` (:122, the number of SEQUENCES, not of amplicons) before scoring the second one:
+ * in the order collect_candidates leaves them (pcr_assay.cpp:39-58: {F(+),R(-)} first, then {R(+),F(-)},
+ * each by sequence, plus site, minus site) an amplicon with an odd index >= the set's sequence count is
+ * never scored.  With evaluate_all_amplicons = 0 that is reproduced bit for bit; with 1 every candidate
+ * amplicon is scored.  (One case stays ours in both modes: an odd amplicon COUNT below num_seq makes the
+ * reference score stale SSE lanes and index past its deque -- undefined there, no extra amplicon here.) */
 int pcr_background_match(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_pairs,
 	const pcr_background_args *args, uint64_t *bits);
 

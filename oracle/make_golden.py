@@ -419,6 +419,93 @@ def amplicons_golden(ref):
     return {"cases": cases}
 
 
+def background_golden(ref):
+    """PCR::find_background_match run by the reference on a small background set, with the candidate amplicon
+    count of every pair: below, equal to and above the number of sequences (background_match.cpp:122 drops the
+    odd-indexed amplicon of a couple once its index reaches num_seq), TaqMAMA on and off.  Pairs whose amplicon
+    count is odd and below num_seq are left out: the reference reads past its deque there (undefined)."""
+    import numpy as np
+    from testdata import mutate
+    PAD = "N" * 40
+    cases = []
+    for ci, kw in enumerate([dict(bg_threshold=0.8, bg_multiplier=0.9, use_taq_mama=0),
+                             dict(bg_threshold=0.75, bg_multiplier=0.9, use_taq_mama=1),
+                             dict(bg_threshold=0.7, bg_multiplier=0.9, use_taq_mama=0, amp_max=400),
+                             dict(bg_threshold=0.45, bg_multiplier=0.9, use_taq_mama=1),
+                             dict(bg_threshold=0.4, bg_multiplier=0.8, use_taq_mama=0, amp_max=400),
+                             dict(bg_threshold=0.35, bg_multiplier=1.0, use_taq_mama=1),
+                             dict(bg_threshold=0.5, bg_multiplier=0.9, use_taq_mama=0, n_extra="equal"),
+                             dict(bg_threshold=0.5, bg_multiplier=0.9, use_taq_mama=1, n_extra="equal+1"),
+                             dict(bg_threshold=0.5, bg_multiplier=0.9, use_taq_mama=1, n_extra="equal-1")]):
+        kw = dict(kw)
+        n_extra = kw.pop("n_extra", None)
+        rng = random.Random(1200 + ci)
+        roots = family_targets(rng, 3, 1, 700, div=0.0)
+        seqs = [mutate(rng, r, 0.05) for r in roots for _ in range(5)]
+        pairs_txt = []
+        while len(pairs_txt) < 16:
+            p = sample_pair(rng, rng.choice(roots))
+            if p:
+                pairs_txt.append(p)
+        pairs = [(ref.centered_word(f), ref.centered_word(r)) for f, r in pairs_txt]
+        thr = float(np.float32(kw["bg_threshold"]) * np.float32(kw["bg_multiplier"]))
+        min_len = int(18 * 0.9)
+
+        def run(seqs, n_pad=0):
+            ses = ref.session()
+            for q in seqs + [PAD] * n_pad:
+                ses.add_target(q, 1.0)
+            n = ses.select(pairs, threshold=thr, min_len_override=min_len)
+            rows = []
+            for pi, p in enumerate(pairs):
+                b, n_amp = ses.background_match(p, **kw)
+                rows.append(None if b is None else [pi, int(n_amp), [int(i) for i in np.nonzero(b)[0]]])
+            return n, rows
+        n_entries, rows = run(seqs)
+        n_pad = 0
+        if n_extra:
+            # pad the set with records that yield no word at all (all-N windows exceed pack_max_degen) until the
+            # sequence count meets an even amplicon count of a pair with hits: index == num_seq exactly on the boundary
+            cand = sorted(r[1] for r in rows if r is not None and r[1] > len(seqs) and r[1] % 2 == 0 and r[2]) or \
+                sorted(r[1] for r in rows if r is not None and r[1] > len(seqs) and r[1] % 2 == 0)
+            assert cand, "no pair with more amplicons than sequences"
+            want = cand[0] + {"equal": 0, "equal+1": 1, "equal-1": -1}[n_extra]
+            n_pad = want - len(seqs)
+            n_entries, rows = run(seqs, n_pad)
+        rows = [r for r in rows if r is not None]
+        n_seq = len(seqs) + n_pad
+        regimes = {"below": sum(r[1] < n_seq for r in rows), "equal": sum(r[1] == n_seq for r in rows), "above": sum(r[1] > n_seq for r in rows)}
+        cases.append({"kw": kw, "seqs": seqs, "n_pad": n_pad, "pad": PAD, "select_threshold": thr, "min_len": min_len, "n_entries": n_entries,
+                      "pairs": [hexw(f) + hexw(r) for f, r in pairs], "rows": rows, "regimes": regimes})
+    return {"cases": cases}
+
+
+def multiplex_match_golden(ref):
+    """PCR::find_multiplex_background_match: F, (F), R, (R) against whole amplicon sequences."""
+    from testdata import mutate
+    cases = []
+    for taq in (0, 1):
+        rng = random.Random(1300 + taq)
+        base = rand_seq(rng, 500)
+        seqs = [base[40:220], mutate(rng, base[40:220], 0.1), rand_seq(rng, 150), base[60:210], rand_seq(rng, 33),
+                mutate(rng, base[30:230], 0.2), revcomp(base[40:220]), rand_seq(rng, 5), base[50:70], base[250:470],
+                mutate(rng, base[250:470], 0.07), rand_seq(rng, 64, p_degen=0.1)]
+        pairs_txt = [(base[50:70], revcomp(base[180:202])), (base[100:125], revcomp(base[300:318])),
+                     (base[260:280], revcomp(base[400:424])), (mutate(rng, base[262:284], 0.1), revcomp(base[395:415]))]
+        f = list(pairs_txt[2][0]); f[7] = "R"; f[12] = "Y"
+        pairs_txt.append(("".join(f), pairs_txt[2][1]))
+        pairs = [(ref.centered_word(a), ref.centered_word(b)) for a, b in pairs_txt]
+        ses = ref.session()
+        for q in seqs:
+            ses.add_target(q, 1.0)
+        rows = []
+        for thr in (0.6, 0.8, 0.95):
+            for pi, p in enumerate(pairs):
+                rows.append([pi, thr, [int(x) for x in ses.multiplex_match(p, thr, taq)]])
+        cases.append({"use_taq_mama": taq, "seqs": seqs, "pairs": [hexw(a) + hexw(b) for a, b in pairs], "rows": rows})
+    return {"cases": cases}
+
+
 def main():
     build_reference()
     ref = Reference()
@@ -427,7 +514,8 @@ def main():
     for name, fn in (("words", words_golden), ("pack", pack_golden), ("screen", screen_golden), ("sw", sw_golden),
                      ("thermo", thermo_golden), ("moves", moves_golden), ("sampler", sampler_golden),
                      ("overlap", overlap_golden), ("multiplex", multiplex_golden),
-                     ("multiplex_optimize", multiplex_optimize_golden), ("amplicons", amplicons_golden)):
+                     ("multiplex_optimize", multiplex_optimize_golden), ("amplicons", amplicons_golden),
+                     ("background", background_golden), ("multiplex_match", multiplex_match_golden)):
         if only and name not in only:
             continue
         with open(os.path.join(OUT, name + ".json"), "w") as f:

@@ -47,7 +47,7 @@ class SwResult(C.Structure):
 
 class BackgroundArgs(C.Structure):
     _fields_ = [("collect_threshold", C.c_float), ("background_threshold", C.c_float), ("amp_min", C.c_int32),
-                ("amp_max", C.c_int32), ("use_taq_mama", C.c_int32)]
+                ("amp_max", C.c_int32), ("use_taq_mama", C.c_int32), ("evaluate_all_amplicons", C.c_int32)]
 
 
 class ThermoArgs(C.Structure):
@@ -459,14 +459,16 @@ class Screener:
         return [(r.score, r.q_start, r.q_stop, r.t_start, r.t_stop, r.last1, r.last2, r.valid) for r in out[:len(queries)]]
 
     def find_background_match(self, pairs, background_threshold=0.8, search_multiplier=0.9, amp_min=0, amp_max=2000,
-                              use_taq_mama=False, which=BACKGROUND):
-        """PCR::find_background_match (background_match.cpp:7) -> bool [n_pairs, n]."""
+                              use_taq_mama=False, which=BACKGROUND, evaluate_all=False):
+        """PCR::find_background_match (background_match.cpp:7) -> bool [n_pairs, n].  evaluate_all=False is the
+        reference bit for bit (the odd-indexed amplicon of a couple is dropped once its index reaches the number
+        of sequences, background_match.cpp:122); True scores every candidate amplicon."""
         a = pairs if isinstance(pairs, np.ndarray) else W.pairs_array(pairs)
         P = a.shape[0]
         nw, n = int(self.bitset_words(which)), self.num_sequences(which)
         bits = np.zeros((P, nw), np.uint64)
         ct = float(np.float32(background_threshold) * np.float32(search_multiplier))
-        args = BackgroundArgs(ct, background_threshold, amp_min, amp_max, int(use_taq_mama))
+        args = BackgroundArgs(ct, background_threshold, amp_min, amp_max, int(use_taq_mama), int(evaluate_all))
         self._check(self.L.pcr_background_match(self.h, which, a.ctypes.data, P, C.byref(args), bits.ctypes.data))
         return np.stack([bits_to_bool(bits[i], n) for i in range(P)]) if P else np.zeros((0, n), bool)
 

@@ -26,6 +26,8 @@
 //   k_sw, k_bg_*, k_mx_*   : SeqOverlap Smith-Waterman and the background / multiplex screens (pcr_sw.inc)
 //   thermo::k_thermo       : NucCruc (pcr_thermo.inc)
 #include <hip/hip_runtime.h>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include <stdint.h>
 #include <string.h>
@@ -598,7 +600,8 @@ struct pcr_ctx {
 	DevBuf<uint64_t> bits_fr, bits_rf;
 	DevBuf<OligoDev> oligos;
 	DevBuf<SwJob> sw_jobs; DevBuf<SwOut> sw_out; DevBuf<uint8_t> sw_q, sw_qlen, sw_t, entry_codes, entry_lens;
-	DevBuf<AmpRec> amp_recs; DevBuf<BgPairDev> bg_pairs;
+	DevBuf<AmpRec> amp_recs, amp_recs2; DevBuf<BgPairDev> bg_pairs;
+	DevBuf<uint64_t> amp_keys; DevBuf<uint32_t> amp_pkeys, amp_pair_start; DevBuf<uint8_t> sort_tmp;   // reference-order sort of the candidate amplicons (order_amplicons)
 	DevBuf<thermo::Job> th_jobs; DevBuf<thermo::JobOut> th_out; DevBuf<int> th_dg, th_scratch_i; DevBuf<unsigned short> th_scratch_s;
 	float th_dg_salt = -1.0f;   // salt the table in th_dg was built for
 	DevBuf<pcr_amplicon> mx_amp;   // pcr_collect_amplicons records
@@ -1135,7 +1138,7 @@ void pcr_destroy(pcr_ctx *ctx)
 	if(ctx->ret_host) (void)hipHostFree(ctx->ret_host);
 	if(ctx->in_host) (void)hipHostFree(ctx->in_host);
 	if(ctx->ret_flag) (void)hipHostFree(ctx->ret_flag);
-	ctx->oligos.release(); ctx->sw_jobs.release(); ctx->sw_out.release(); ctx->sw_q.release(); ctx->sw_qlen.release(); ctx->sw_t.release(); ctx->entry_codes.release(); ctx->entry_lens.release(); ctx->amp_recs.release(); ctx->bg_pairs.release(); ctx->th_jobs.release(); ctx->th_out.release(); ctx->th_dg.release(); ctx->th_scratch_i.release(); ctx->th_scratch_s.release(); ctx->mx_keys.release(); ctx->mx_count.release(); ctx->mx_amp.release();
+	ctx->oligos.release(); ctx->sw_jobs.release(); ctx->sw_out.release(); ctx->sw_q.release(); ctx->sw_qlen.release(); ctx->sw_t.release(); ctx->entry_codes.release(); ctx->entry_lens.release(); ctx->amp_recs.release(); ctx->amp_recs2.release(); ctx->amp_keys.release(); ctx->amp_pkeys.release(); ctx->amp_pair_start.release(); ctx->sort_tmp.release(); ctx->bg_pairs.release(); ctx->th_jobs.release(); ctx->th_out.release(); ctx->th_dg.release(); ctx->th_scratch_i.release(); ctx->th_scratch_s.release(); ctx->mx_keys.release(); ctx->mx_count.release(); ctx->mx_amp.release();
 	if(ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 }

@@ -211,3 +211,41 @@ def test_collect_amplicons_golden(ci):
             assert got == set(row["amplicons"])
     finally:
         d.close()
+
+
+@pytest.mark.parametrize("ci", range(9))
+def test_background_golden(ci):
+    """pcr_background_match in its default (reference-identical) mode against the compiled reference's own
+    find_background_match (tests/golden/background.json): candidate amplicon counts below, equal to and above the
+    number of sequences, where background_match.cpp:122 drops the odd-indexed amplicon of every couple."""
+    with open(os.path.join(G, "background.json")) as f:
+        c = json.load(f)["cases"][ci]
+    seqs = c["seqs"] + [c["pad"]] * c["n_pad"]
+    kw = c["kw"]
+    d = api.Screener(0)
+    try:
+        d.load_texts(seqs, which=api.BACKGROUND)
+        pairs = [((int(p[0], 16), int(p[1], 16)), (int(p[2], 16), int(p[3], 16))) for p in c["pairs"]]
+        assert d.select_words(pairs, c["select_threshold"], c["min_len"], which=api.BACKGROUND) == c["n_entries"]
+        bits = d.find_background_match(pairs, kw["bg_threshold"], kw["bg_multiplier"], 0, kw.get("amp_max", 2000), kw["use_taq_mama"])
+        for pi, n_amp, want in c["rows"]:
+            assert np.nonzero(bits[pi])[0].tolist() == want, (ci, pi, n_amp)
+    finally:
+        d.close()
+
+
+@pytest.mark.parametrize("ci", range(2))
+def test_multiplex_match_golden(ci):
+    with open(os.path.join(G, "multiplex_match.json")) as f:
+        c = json.load(f)["cases"][ci]
+    d = api.Screener(0)
+    try:
+        d.load_texts(c["seqs"], which=api.BACKGROUND)
+        pairs = [((int(p[0], 16), int(p[1], 16)), (int(p[2], 16), int(p[3], 16))) for p in c["pairs"]]
+        for thr in sorted(set(r[1] for r in c["rows"])):
+            bits = d.find_multiplex_background_match(pairs, thr, c["use_taq_mama"])
+            for pi, t, want in c["rows"]:
+                if t == thr:
+                    assert bits[pi].astype(int).tolist() == want, (ci, pi, thr)
+    finally:
+        d.close()

@@ -85,14 +85,22 @@ def test_background_match(dev, oracle, kw):
     min_len = int(18 * 0.9)
     dev.load_texts(seqs, which=api.BACKGROUND)
     assert dev.select_words(pairs, thr, min_len, which=api.BACKGROUND) == so.select(pairs, threshold=thr, min_len_override=min_len)
+    # default = the reference bit for bit (odd-indexed amplicons at or beyond the sequence count are never scored,
+    # background_match.cpp:122); evaluate_all = every candidate amplicon
     bits = dev.find_background_match(pairs, kw["bg_threshold"], kw["bg_multiplier"], 0, kw.get("amp_max", 2000),
                                      kw["use_taq_mama"])
-    hits = 0
+    bits_all = dev.find_background_match(pairs, kw["bg_threshold"], kw["bg_multiplier"], 0, kw.get("amp_max", 2000),
+                                         kw["use_taq_mama"], evaluate_all=True)
+    hits = differ = 0
     for k, p in enumerate(pairs):
-        ob, _ = so.background_match(p, **kw)
+        ob, _ = so.background_match(p, emulate_index_bug=1, **kw)
+        oa, _ = so.background_match(p, emulate_index_bug=0, **kw)
         assert (bits[k] == ob.astype(bool)).all(), k
+        assert (bits_all[k] == oa.astype(bool)).all(), k
         hits += int(ob.sum())
+        differ += int((ob != oa).any())
     assert hits > 0 or kw["bg_threshold"] > 0.5
+    assert differ > 0 or kw["bg_threshold"] > 0.5        # the two modes are told apart on this input
 
 
 @pytest.mark.parametrize("taq", [0, 1])

@@ -223,3 +223,44 @@ def test_collect_amplicons(oracle, ci):
         b, a = sess.collect_amplicons(p, o["target_threshold"], o["amp_min"], o["amp_max"])
         assert [list(x) for x in b] == row["bounds"]
         assert ["".join("%x" % v for v in t) for t in a] == row["amplicons"]
+
+
+def _pairs(c):
+    return [((int(p[0], 16), int(p[1], 16)), (int(p[2], 16), int(p[3], 16))) for p in c["pairs"]]
+
+
+@pytest.mark.parametrize("ci", range(9))
+def test_background_match(oracle, ci):
+    """find_background_match of the compiled reference (tests/golden/background.json): amplicon counts below,
+    equal to and above the number of sequences; the oracle in its reference-identical mode."""
+    c = load("background")["cases"][ci]
+    seqs = c["seqs"] + [c["pad"]] * c["n_pad"]
+    s = oracle.session()
+    for q in seqs:
+        s.add_target(q)
+    pairs = _pairs(c)
+    assert s.select(pairs, threshold=c["select_threshold"], min_len_override=c["min_len"]) == c["n_entries"]
+    for pi, n_amp, want in c["rows"]:
+        got, _ = s.background_match(pairs[pi], emulate_index_bug=1, **c["kw"])
+        assert np.nonzero(got)[0].tolist() == want, (ci, pi, n_amp)
+
+
+def test_background_golden_covers_the_regimes():
+    cases = load("background")["cases"]
+    tot = {k: sum(c["regimes"][k] for c in cases) for k in ("below", "equal", "above")}
+    assert tot["below"] >= 5 and tot["equal"] >= 2 and tot["above"] >= 50
+    assert sum(len(r[2]) for c in cases for r in c["rows"]) > 200
+
+
+@pytest.mark.parametrize("ci", range(2))
+def test_multiplex_match(oracle, ci):
+    c = load("multiplex_match")["cases"][ci]
+    s = oracle.session()
+    for q in c["seqs"]:
+        s.add_target(q)
+    pairs = _pairs(c)
+    hits = 0
+    for pi, thr, want in c["rows"]:
+        assert s.multiplex_match(pairs[pi], thr, c["use_taq_mama"]).tolist() == want
+        hits += sum(want)
+    assert hits > 10
