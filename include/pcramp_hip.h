@@ -230,10 +230,10 @@ typedef struct {
 typedef struct {
 	uint32_t valid;        /* PCR::is_valid(): every IUPAC expansion passes all enabled tests */
 	uint32_t n_expansions; /* Word::degeneracy() as an integer */
-	float tm, dH, dS;      /* NucCruc::tm_pm_duplex / delta_H / delta_S of the FIRST expansion (Word::begin()) */
+	float tm, dH, dS;      /* NucCruc::tm_pm_duplex / delta_H / delta_S of the FIRST expansion (Word::begin()); kcal/mol, kcal/(mol K) */
 	float hairpin_tm;      /* approximate_tm_hairpin of the first expansion */
 	float homodimer_tm;    /* approximate_tm_homodimer of the first expansion (0 unless check_homo_dimer) */
-	uint32_t pad;
+	float dG;              /* NucCruc::delta_G() = dH - 310.15 K * dS of the perfect-match duplex (nuc_cruc.h:1375-1378), first expansion */
 } pcr_thermo_result;
 
 /* PCR::is_valid (valid_pcr.cpp:5-45) for n oligos: perfect-match duplex Tm in [tm_min, tm_max],

@@ -72,7 +72,7 @@ class SampleInfo(C.Structure):
 
 class ThermoResult(C.Structure):
     _fields_ = [("valid", C.c_uint32), ("n_expansions", C.c_uint32), ("tm", C.c_float), ("dH", C.c_float), ("dS", C.c_float),
-                ("hairpin_tm", C.c_float), ("homodimer_tm", C.c_float), ("pad", C.c_uint32)]
+                ("hairpin_tm", C.c_float), ("homodimer_tm", C.c_float), ("dG", C.c_float)]
 
 
 class AmplifyArgs(C.Structure):
@@ -498,7 +498,7 @@ class Screener:
         if flags:
             return np.frombuffer(out, dtype=np.uint32).reshape(-1, 8)[:len(oligos), 0] != 0
         return [dict(valid=bool(r.valid), n=r.n_expansions, tm=np.float32(r.tm), dH=np.float32(r.dH), dS=np.float32(r.dS),
-                     hairpin_tm=np.float32(r.hairpin_tm), homodimer_tm=np.float32(r.homodimer_tm)) for r in out[:len(oligos)]]
+                     hairpin_tm=np.float32(r.hairpin_tm), homodimer_tm=np.float32(r.homodimer_tm), dG=np.float32(r.dG)) for r in out[:len(oligos)]]
 
     def collect_amplicons(self, pair, threshold=1.0, amp_min=80, amp_max=200, which=TARGET, cap=4096):
         """PCR::collect_unique_amplicons: -> [dict(sequence, begin, end, inner_start, inner_length, orientation)]

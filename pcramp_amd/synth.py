@@ -22,29 +22,43 @@ CONFIGS = {
 }
 
 _ACGT = np.array([1, 2, 4, 8], dtype=np.uint8)
+_LOG2 = np.array([0, 0, 1, 0, 2, 0, 0, 0, 3], dtype=np.uint8)
 
 
 def _rng(seed):
     return np.random.Generator(np.random.MT19937(seed))
 
 
-def make_sequences(T, L, seed, family=50, divergence=0.03, chunk=256):
-    """-> (packed uint8 [sum ceil(L/2)], byte_offsets uint64[T], lengths uint64[T], codes_of(i) callable)."""
+def make_sequences(T, L, seed, family=50, divergence=0.03, chunk=256, n_roots=None, root_of=None):
+    """-> (packed uint8 [sum ceil(L/2)], byte_offsets uint64[T], lengths uint64[T]).
+    The roots are the FIRST draw of the seed's stream, so another call with the same (seed, L, n_roots) derives
+    its members from the same roots (the backgrounds of a config: `root_of` maps member -> root)."""
     rng = _rng(seed)
-    n_fam = (T + family - 1) // family
+    n_fam = (T + family - 1) // family if n_roots is None else n_roots
     roots = _ACGT[rng.integers(0, 4, size=(n_fam, L), dtype=np.uint8)]
     nb = (L + 1) // 2
     packed = np.empty(T * nb, dtype=np.uint8)
-    fam_of = np.arange(T) // family
+    fam_of = np.arange(T) // family if root_of is None else np.asarray(root_of)
+    if root_of is not None:
+        rng = _rng(seed ^ 0xBAC6)                           # the members' own stream (the targets keep the seed's)
     chunk = max(1, min(chunk, (32 << 20) // max(L, 1)))     # bound the temporaries (~20 B per base of a chunk)
     for lo in range(0, T, chunk):
         hi = min(T, lo + chunk)
         c = roots[fam_of[lo:hi]].copy()
-        mut = rng.random(c.shape, dtype=np.float32) < divergence
-        # a substitution always changes the base: rotate the one-hot code by 1..3 positions
-        rot = rng.integers(1, 4, size=c.shape, dtype=np.uint8)
-        idx = np.log2(c).astype(np.uint8)
-        c = np.where(mut, _ACGT[(idx + rot) & 3], c)
+        if L >= 1000000:
+            # genome-sized members: draw the substituted positions instead of a coin per base (a position drawn
+            # twice is substituted once, so the rate is 3 % less one part in thirty)
+            n_mut = int(round(L * divergence))
+            for m in range(hi - lo):
+                pos = rng.integers(0, L, size=n_mut)
+                rot = rng.integers(1, 4, size=n_mut, dtype=np.uint8)
+                c[m, pos] = _ACGT[(_LOG2[c[m, pos]] + rot) & 3]
+        else:
+            mut = rng.random(c.shape, dtype=np.float32) < divergence
+            # a substitution always changes the base: rotate the one-hot code by 1..3 positions
+            rot = rng.integers(1, 4, size=c.shape, dtype=np.uint8)
+            idx = np.log2(c).astype(np.uint8)
+            c = np.where(mut, _ACGT[(idx + rot) & 3], c)
         if L & 1:
             c = np.concatenate([c, np.zeros((hi - lo, 1), np.uint8)], axis=1)
         packed[lo * nb:hi * nb] = ((c[:, 0::2] << 4) | c[:, 1::2]).reshape(-1)
@@ -59,12 +73,13 @@ def sequence_codes(packed, byte_offsets, lengths, i):
     return W.unpack_codes(packed[o:o + nb], int(lengths[i]))
 
 
-def make_pairs(packed, byte_offsets, lengths, P, seed, primer=(18, 25), amplicon=(80, 200), degenerate=0):
+def make_pairs(packed, byte_offsets, lengths, P, seed, primer=(18, 25), amplicon=(80, 200), degenerate=0, origins_out=None):
     """P primer pairs sampled from the sequences; `degenerate` > 0 widens that many positions
     per primer to a 2-fold IUPAC code (degeneracy <= 2**degenerate)."""
     rng = _rng(seed ^ 0x5EED)
     T = len(lengths)
     pairs = []
+    origins = [] if origins_out is None else origins_out
     while len(pairs) < P:
         t = int(rng.integers(0, T))
         L = int(lengths[t])
@@ -84,14 +99,37 @@ def make_pairs(packed, byte_offsets, lengths, P, seed, primer=(18, 25), amplicon
                 k = int(rng.integers(0, o.size))
                 o[k] |= _ACGT[int(rng.integers(0, 4))]
         pairs.append((W.centered_word(f), W.centered_word(r)))
+        origins.append((t, fs, amp))
     return pairs
 
 
-def workload(name, seed_offset=0, scale=1.0):
-    """-> dict(packed, byte_offsets, lengths, pairs, T, L, P).  `scale` < 1 shrinks T (CPU baselines)."""
+def workload(name, seed_offset=0, scale=1.0, family=50):
+    """-> dict(packed, byte_offsets, lengths, pairs, origins, T, L, P [, background = dict(packed, byte_offsets,
+    lengths, B, L, root_of)]).  `scale` < 1 shrinks T and B (CPU baselines).  origins[k] = (target, start, amplicon
+    length) the k-th pair was cut from.  Backgrounds (C3): B sequences, member i = root (i mod n_roots) of the TARGET
+    families with 15 % substitutions."""
     cfg = dict(CONFIGS[name])
     T = max(1, int(round(cfg["T"] * scale)))
     seed = BASE_SEED + {"C1": 1, "C2": 2, "C3": 3, "C4_shard": 4, "C5_shard": 5}[name] + 1000 * seed_offset
-    packed, off, lens = make_sequences(T, cfg["L"], seed)
-    pairs = make_pairs(packed, off, lens, cfg["P"], seed, degenerate=cfg.get("degenerate", 0))
-    return dict(packed=packed, byte_offsets=off, lengths=lens, pairs=pairs, T=T, L=cfg["L"], P=cfg["P"], name=name)
+    packed, off, lens = make_sequences(T, cfg["L"], seed, family=family)
+    origins = []
+    pairs = make_pairs(packed, off, lens, cfg["P"], seed, degenerate=cfg.get("degenerate", 0), origins_out=origins)
+    out = dict(packed=packed, byte_offsets=off, lengths=lens, pairs=pairs, origins=origins, T=T, L=cfg["L"], P=cfg["P"], name=name,
+               family=family)
+    if cfg.get("B"):
+        if cfg["LB"] != cfg["L"]:
+            raise ValueError("backgrounds are mutated target roots: LB must equal L")
+        B = max(1, int(round(cfg["B"] * scale)))
+        n_roots = (T + family - 1) // family
+        root_of = np.arange(B) % n_roots
+        bp, bo, bl = make_sequences(B, cfg["LB"], seed, family=family, divergence=0.15, n_roots=n_roots, root_of=root_of)
+        out["background"] = dict(packed=bp, byte_offsets=bo, lengths=bl, B=B, L=cfg["LB"], root_of=root_of)
+    return out
+
+
+def subset(wl_set, idx, L):
+    """(packed, byte_offsets, lengths) of the listed sequences of a workload's target or background set."""
+    nb = (L + 1) // 2
+    idx = [int(i) for i in idx]
+    packed = np.concatenate([wl_set["packed"][int(wl_set["byte_offsets"][i]):int(wl_set["byte_offsets"][i]) + nb] for i in idx])
+    return packed, np.arange(len(idx), dtype=np.uint64) * np.uint64(nb), np.full(len(idx), L, dtype=np.uint64)

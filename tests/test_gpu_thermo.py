@@ -50,8 +50,8 @@ def test_oligo_thermo_matches_oracle(dev, oracle, salt, strand):
     exact = tot = 0
     for s, r in zip(seqs, res):
         o = oracle.thermo_full(s, salt, strand)
-        got = [r["tm"], r["dH"], r["dS"], r["hairpin_tm"], r["homodimer_tm"]]
-        want = [o[0], o[1], o[2], o[4], o[7]]
+        got = [r["tm"], r["dH"], r["dS"], r["dG"], r["hairpin_tm"], r["homodimer_tm"]]
+        want = [o[0], o[1], o[2], o[3], o[4], o[7]]
         for g, w in zip(got, want):
             assert close(g, w), (s, got, want)
             exact += int(np.float32(g) == np.float32(w)); tot += 1
