@@ -332,6 +332,60 @@ float pcr_host_oligo_overlap(const pcr_pair *assay, const pcr_pair *pool, uint32
 /* glibc rand_r (the reference's random source, sample.cpp:12), restated; usable without a GPU. */
 uint32_t pcr_host_rand_r(uint32_t *seed);
 
+/* ---- Assay-list writers (scope row f-4): the bytes `pcramp` writes to its output file.  Host only. */
+
+/* What the writers read besides the assay itself (Options::output_format, opt.use_multiplex, the sequence records). */
+typedef struct {
+	int32_t json;                        /* 0 = Options::TEXT_OUTPUT, 1 = Options::JSON_OUTPUT (pcramp.h, --o.text / --o.json) */
+	int32_t use_multiplex;               /* opt.use_multiplex (always true in v0.3, options.cpp:72): reused oligos are marked */
+	uint32_t n_target, n_background;
+	const char *const *target_deflines;       /* Sequence::defline(); keeps the leading '>' (parse_fasta.cpp:58) */
+	const char *const *background_deflines;
+	const uint64_t *target_lengths;           /* Sequence::length(), for sequence_summary (main.cpp:1326-1400) */
+	const uint64_t *background_lengths;
+} pcr_output;
+
+/* One accepted assay as main.cpp:950-1113 writes it. */
+typedef struct {
+	uint32_t major_id, minor_id;              /* main.cpp:468-502 */
+	pcr_pair assay;                           /* best_assay */
+	float target_coverage, background_coverage;        /* best_score */
+	float active_target_norm, active_background_norm;  /* summed weights of the active sequences (main.cpp:603,649) */
+	uint32_t num_active_background;           /* main.cpp:565-569 */
+	const uint64_t *target_match;             /* best_target_match: BitSet words, bit i%64 of word i/64 */
+	const uint64_t *background_match;         /* best_background_match (may be NULL when there are no backgrounds) */
+} pcr_assay_record;
+
+/* All writers return the number of bytes of the text (the NUL is not counted) or a negative error; at most `cap`
+ * bytes are stored (NUL-terminated when they fit), so a first call with cap = 0 sizes the buffer. */
+
+/* PCR::write(ostream&) / write(ostream&, pool) / write_json(ostream&) / write_json(ostream&, pool), assay.h:288-375:
+ * "F\tR\tD(F)=..;D(R)=.." with reused oligos in lower case (text), or the two primer objects with "recycled":True|False
+ * (JSON).  use_multiplex = 0 selects the pool-less forms. */
+int64_t pcr_format_oligos(const pcr_pair *assay, const pcr_pair *pool, uint32_t n_pool, int json, int use_multiplex,
+	char *out, uint64_t cap);
+
+/* Version, command line and seed (main.cpp:131-163), both sequence summaries (main.cpp:440-443) and, for JSON, the
+ * opening of the assay array (main.cpp:460-462). */
+int64_t pcr_format_header(const pcr_output *o, int argc, const char *const *argv, uint32_t seed, char *out, uint64_t cap);
+
+/* What every design iteration writes BEFORE the search (main.cpp:504-519): the rule and "# Attempting to detect N
+ * remaining targets" (text) or the record opening with its id (JSON).  The reference writes it even if the iteration
+ * then finds no assay. */
+int64_t pcr_format_iteration(const pcr_output *o, uint32_t assay_iteration, uint32_t major_id, uint32_t minor_id,
+	uint32_t targets_remaining, char *out, uint64_t cap);
+
+/* One accepted assay (main.cpp:950-1113): score line + "ASSAY.M.m" + oligos + "T-"/"B-" deflines (text), or the primer
+ * objects + "target matches" + "background matches" (JSON).  pool = the assays accepted before this one. */
+int64_t pcr_format_assay(const pcr_output *o, const pcr_assay_record *rec, const pcr_pair *pool, uint32_t n_pool,
+	char *out, uint64_t cap);
+
+/* The end of the file (main.cpp:1132-1264): targets still active (= not detected), background sequences any accepted
+ * assay cross-reacted with (total_background = OR of the pool's background bitsets; may be NULL).  The JSON form
+ * leaves the final "background matches" array unclosed when it is not empty, as the reference does (main.cpp:1235-1259). */
+int64_t pcr_format_footer(const pcr_output *o, const uint8_t *target_active, const uint64_t *total_background,
+	char *out, uint64_t cap);
+
 /* ---- Host-only helpers (pure CPU arithmetic of the host half of the index build; usable
  * without a GPU; exercised by the `not gpu` tests). */
 

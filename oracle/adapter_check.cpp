@@ -1,0 +1,178 @@
+// TEST INFRASTRUCTURE ONLY: the reference-side adapter of INTEGRATION.md section 1, with real bodies, compiled against
+// the reference's own headers (assay.h, sequence.h, bitset.h, pcramp.h where they lie under /root/reference) and
+// against include/pcramp_hip.h -- `make -C oracle adapter`.  It proves that the binding a maintainer would add
+// type-checks against both sides: Word <-> pcr_word128, PCR <-> pcr_pair, deque<Sequence> -> pcr_load_sequences,
+// BitSet <- bitset words, Options -> the argument structs, errors re-thrown as `const char*` (main.cpp:1269).
+// Nothing here is copied from the reference; it only CALLS its public interface.
+#include <deque>
+#include <vector>
+#include <string>
+#include <string.h>
+
+#include "pcramp_hip.h"
+#include "assay.h"          // PCR, Word, Sequence, BitSet, Options, Score (reference headers)
+
+struct DeviceScreen {       // one per process (one GPU); not thread-safe, like one NucCruc per thread (main.cpp:533,702)
+	pcr_ctx *ctx;
+
+	explicit DeviceScreen(const Options &opt, int device = 0)
+	{
+		pcr_params p = { opt.pack_max_degen, opt.pack_min_gc, opt.pack_max_gc };
+		ctx = pcr_create(device, NULL, &p);
+		if(!ctx) throw pcr_last_error();                 // reference error convention: throw const char*
+	}
+	~DeviceScreen() { pcr_destroy(ctx); }
+
+	static pcr_word128 W(const Word &w)                  // Word is two u64 in exactly the ABI layout (word.h:673-679)
+	{
+		pcr_word128 r; unsigned char b[16]; w.mpi_pack(b); memcpy(r.w, b, 16); return r;
+	}
+	static Word W(const pcr_word128 &w)
+	{
+		Word r; unsigned char b[16]; memcpy(b, w.w, 16); r.mpi_unpack(b); return r;
+	}
+	static pcr_pair P(const PCR &a) { pcr_pair r = { W(a.oligo(FORWARD)), W(a.oligo(REVERSE)) }; return r; }
+	static void check(int rc) { if(rc != PCR_OK) throw pcr_last_error(); }
+
+	// after parse_fasta (main.cpp:257-344): hand the deque<Sequence> over once.  seq_buffer is private, so the codes are
+	// read through Sequence::operator[] and re-packed two per byte, high nibble first (sequence.h:223-228).
+	void load(pcr_set which, const std::deque<Sequence> &seq)
+	{
+		std::vector<uint64_t> off(seq.size()), len(seq.size());
+		std::vector<float> weight(seq.size());
+		std::vector<uint8_t> packed;
+		for(size_t s = 0;s < seq.size();++s){
+			off[s] = packed.size(); len[s] = seq[s].length(); weight[s] = seq[s].weight();
+			for(size_t i = 0;i < seq[s].length();i += 2){
+				const unsigned hi = seq[s][(unsigned)i], lo = (i + 1 < seq[s].length()) ? seq[s][(unsigned)(i + 1)] : 0u;
+				packed.push_back((uint8_t)((hi << 4) | lo));
+			}
+		}
+		check(pcr_load_sequences(ctx, which, packed.data(), off.data(), len.data(), weight.data(), (uint32_t)seq.size()));
+		set_active(which, seq);
+	}
+	void set_active(pcr_set which, const std::deque<Sequence> &seq)                  // main.cpp:1105-1120
+	{
+		std::vector<uint8_t> a(seq.size());
+		for(size_t s = 0;s < seq.size();++s) a[s] = seq[s].active() ? 1 : 0;
+		check(pcr_set_active(ctx, which, a.data()));
+	}
+	void split(pcr_set which, unsigned idx, unsigned pos) { check(pcr_split(ctx, which, idx, pos)); }   // main.cpp:1008-1017
+
+	// main.cpp:644-691 / 579-615: the per-iteration index build for all trial assays
+	uint64_t select_words(pcr_set which, const std::vector<PCR> &trial, const Options &opt)
+	{
+		std::vector<pcr_pair> p(trial.size());
+		for(size_t i = 0;i < trial.size();++i) p[i] = P(trial[i]);
+		uint64_t n = 0;
+		const bool bg = (which == PCR_SET_BACKGROUND);
+		const float thr = bg ? opt.background_threshold*opt.background_search_multiplier : opt.target_threshold*opt.target_search_multiplier;
+		const unsigned min_len = bg ? (unsigned)(opt.min_oligo_length()*0.9) : opt.min_oligo_length();   // main.cpp:595
+		check(pcr_select_words(ctx, which, p.data(), (uint32_t)p.size(), opt.optimize_5, opt.optimize_3, thr, min_len, &n));
+		return n;
+	}
+
+	static void to_bitset(BitSet &m, const std::vector<uint64_t> &w)
+	{
+		for(size_t i = 0;i < m.size();++i) m[i] = (w[i >> 6] >> (i & 63)) & 1u;
+	}
+
+	// main.cpp:898: best_assay.find_target_match(best_target_match, ...)
+	void find_target_match(BitSet &m, const PCR &a, const Options &opt)
+	{
+		const pcr_pair p = P(a);
+		pcr_amplify_args args = { opt.target_threshold, opt.target_threshold, opt.target_amplicon_range.first,
+			opt.target_amplicon_range.second, opt.use_taq_mama ? 1 : 0 };
+		std::vector<uint64_t> bits(pcr_bitset_words(ctx, PCR_SET_TARGET));
+		check(pcr_amplify(ctx, PCR_SET_TARGET, &p, 1, &args, bits.data(), NULL, NULL, NULL));
+		to_bitset(m, bits);
+	}
+
+	// optimize.cpp:61-77: collect + update + compute_target_coverage of one assay
+	float target_coverage(const PCR &a, const Options &opt)
+	{
+		const pcr_pair p = P(a);
+		pcr_amplify_args args = { opt.target_threshold*opt.target_search_multiplier, opt.target_threshold,
+			opt.target_amplicon_range.first, opt.target_amplicon_range.second, opt.use_taq_mama ? 1 : 0 };
+		float cov = 0.0f;
+		check(pcr_amplify(ctx, PCR_SET_TARGET, &p, 1, &args, NULL, NULL, NULL, &cov));
+		return cov;
+	}
+
+	// main.cpp:824: find_background_match (reference-identical amplicon pairing, background_match.cpp:122)
+	void find_background_match(BitSet &m, const PCR &a, const Options &opt)
+	{
+		const pcr_pair p = P(a);
+		pcr_background_args args = { opt.background_threshold*opt.background_search_multiplier, opt.background_threshold,
+			opt.background_amplicon_range.first, opt.background_amplicon_range.second, opt.use_taq_mama ? 1 : 0, 0 };
+		std::vector<uint64_t> bits(pcr_bitset_words(ctx, PCR_SET_BACKGROUND));
+		check(pcr_background_match(ctx, PCR_SET_BACKGROUND, &p, 1, &args, bits.data()));
+		to_bitset(m, bits);
+	}
+
+	static pcr_thermo_args thermo_args(const Options &opt)
+	{
+		pcr_thermo_args t = { opt.salt, opt.primer_strand, opt.primer_tm_range.first, opt.primer_tm_range.second, opt.max_hairpin, opt.max_dimer };
+		return t;
+	}
+
+	// valid_pcr.cpp:5-45 for a batch of oligos (every move variant of optimize_pcr.cpp)
+	std::vector<bool> is_valid(const std::vector<Word> &oligos, bool check_homo_dimer, const Options &opt)
+	{
+		std::vector<pcr_word128> w(oligos.size());
+		for(size_t i = 0;i < oligos.size();++i) w[i] = W(oligos[i]);
+		std::vector<pcr_thermo_result> r(oligos.size());
+		const pcr_thermo_args t = thermo_args(opt);
+		check(pcr_thermo(ctx, w.data(), (uint32_t)w.size(), check_homo_dimer ? 1 : 0, &t, r.data()));
+		std::vector<bool> ok(oligos.size());
+		for(size_t i = 0;i < oligos.size();++i) ok[i] = r[i].valid != 0;
+		return ok;
+	}
+
+	// main.cpp:538-550 at one thread: the trial assays of a design iteration
+	void random_assays(std::vector<PCR> &trial, unsigned *global_seed, const Options &opt)
+	{
+		uint32_t local = pcr_host_rand_r(global_seed);
+		pcr_sampler_args sa = { opt.primer_range.first, opt.primer_range.second, opt.target_amplicon_range.first,
+			opt.target_amplicon_range.second, opt.degen };
+		const pcr_thermo_args t = thermo_args(opt);
+		std::vector<pcr_pair> p(trial.size());
+		check(pcr_random_assays(ctx, PCR_SET_TARGET, &local, (uint32_t)trial.size(), &sa, &t, p.data(), NULL));
+		for(size_t i = 0;i < trial.size();++i){ trial[i].oligo(FORWARD, W(p[i].f)); trial[i].oligo(REVERSE, W(p[i].r)); }
+	}
+
+	// main.cpp:950-1113 in text form through the ABI's writer (the deflines keep their '>')
+	std::string assay_text(const PCR &a, const std::deque<PCR> &pool)
+	{
+		const pcr_pair p = P(a);
+		std::vector<pcr_pair> q(pool.size());
+		for(size_t i = 0;i < pool.size();++i) q[i] = P(pool[i]);
+		const int64_t n = pcr_format_oligos(&p, q.data(), (uint32_t)q.size(), 0, 1, NULL, 0);
+		if(n < 0) throw pcr_last_error();
+		std::string s((size_t)n + 1, '\0');
+		pcr_format_oligos(&p, q.data(), (uint32_t)q.size(), 0, 1, &s[0], (uint64_t)n + 1);
+		s.resize((size_t)n);
+		return s;
+	}
+};
+
+// one function that instantiates every member, so that the whole adapter is compiled and linked, not only parsed
+extern "C" int adapter_check_touch(int run)
+{
+	if(!run) return 0;
+	Options opt;
+	DeviceScreen d(opt);
+	std::deque<Sequence> seq;
+	d.load(PCR_SET_TARGET, seq);
+	d.split(PCR_SET_TARGET, 0, 0);
+	std::vector<PCR> trial(2);
+	unsigned seed = 1;
+	d.random_assays(trial, &seed, opt);
+	d.select_words(PCR_SET_TARGET, trial, opt);
+	BitSet m(0, false);
+	d.find_target_match(m, trial[0], opt);
+	d.find_background_match(m, trial[0], opt);
+	const float c = d.target_coverage(trial[0], opt);
+	const std::vector<bool> ok = d.is_valid(std::vector<Word>(1, trial[0].oligo(FORWARD)), true, opt);
+	return (int)c + (int)ok.size() + (int)d.assay_text(trial[0], std::deque<PCR>()).size();
+}

@@ -506,6 +506,67 @@ def multiplex_match_golden(ref):
     return {"cases": cases}
 
 
+def writers_golden(ref):
+    """Scope row f-4.  (a) PCR::write / write_json in their four forms for assays and pools with reused oligos
+    (through the harness); (b) whole output files of the reference PROGRAM (oracle/_ref/pcramp = main.cpp linked with
+    the same objects), one rank, one thread, fixed seed, on toy FASTA files: text and JSON."""
+    import subprocess
+    import tempfile
+    rng = random.Random(4711)
+    oligos = []
+    for it in range(40):
+        f = ref.centered_word(rand_seq(rng, rng.randint(18, 25), p_degen=0.08 if it % 2 else 0.0))
+        r = ref.centered_word(rand_seq(rng, rng.randint(18, 25), p_degen=0.08 if it % 3 == 0 else 0.0))
+        pool = [(ref.centered_word(rand_seq(rng, rng.randint(18, 25))), ref.centered_word(rand_seq(rng, rng.randint(18, 25))))
+                for _ in range(rng.randint(0, 4))]
+        if it % 4 == 1:
+            pool.append((r, pool[0][0] if pool else f))          # the reverse oligo is reused
+        if it % 4 == 2:
+            pool.insert(0, (f, f))                               # the forward oligo is reused
+        if it % 8 == 3:
+            pool.append((ref.word_shift_right(f), r))            # same oligos, one of them shifted inside the word
+        forms = {}
+        for json_ in (0, 1):
+            for with_pool in (0, 1):
+                forms["%d%d" % (json_, with_pool)] = ref.format_oligos((f, r), pool, json_, with_pool).decode("latin-1")
+        oligos.append({"assay": hexw(f) + hexw(r), "pool": [hexw(a) + hexw(b) for a, b in pool], "forms": forms})
+
+    from testdata import mutate
+    exe = os.path.join(ROOT, "oracle", "_ref", "pcramp")
+    runs = []
+    with tempfile.TemporaryDirectory() as tmp:
+        libdir = os.path.join(tmp, "lib")
+        os.makedirs(libdir)
+        for so in ("libmpi.so.12", "libgfortran.so.4", "libquadmath.so.0"):      # not the whole conda lib dir: its libstdc++ is older
+            os.symlink(os.path.join("/opt/conda/lib", so), os.path.join(libdir, so))
+        env = dict(os.environ, LD_LIBRARY_PATH=libdir, OMP_NUM_THREADS="1")
+        specs = [dict(n_fam=3, per=4, L=600, n_bg=2, args=["--count", "3", "--trial", "40", "--seed", "42"]),
+                 dict(n_fam=3, per=4, L=600, n_bg=2, args=["--count", "3", "--trial", "40", "--seed", "42", "--o.json"]),
+                 dict(n_fam=1, per=4, L=500, n_bg=0, args=["--count", "3", "--trial", "60", "--seed", "7", "-d", "8"]),
+                 dict(n_fam=1, per=4, L=500, n_bg=0, args=["--count", "3", "--trial", "60", "--seed", "7", "-d", "8", "--o.json"]),
+                 dict(n_fam=2, per=3, L=451, n_bg=3, args=["--count", "6", "--trial", "30", "--seed", "99", "--target.threshold", "0.9"]),
+                 dict(n_fam=2, per=3, L=451, n_bg=3, args=["--count", "6", "--trial", "30", "--seed", "99", "--target.threshold", "0.9", "--o.json"])]
+        for si, sp in enumerate(specs):
+            r2 = random.Random(6000 + si // 2)
+            roots = [rand_seq(r2, sp["L"] + 7 * k) for k in range(sp["n_fam"])]
+            targets = [(">target_%d family %d" % (k * sp["per"] + j, k), mutate(r2, roots[k], 0.03)) for k in range(sp["n_fam"]) for j in range(sp["per"])]
+            bgs = [(">bg_%d" % i, mutate(r2, roots[i % len(roots)], 0.12)) for i in range(sp["n_bg"])]
+            with open(os.path.join(tmp, "t.fa"), "w") as f:
+                f.write("".join("%s\n%s\n" % (d, q) for d, q in targets))
+            argv = ["pcramp", "-t", "t.fa", "-o", "out.txt", "--thread", "1"] + sp["args"]
+            if bgs:
+                with open(os.path.join(tmp, "b.fa"), "w") as f:
+                    f.write("".join("%s\n%s\n" % (d, q) for d, q in bgs))
+                argv += ["-b", "b.fa"]
+            subprocess.check_call([exe] + argv[1:], cwd=tmp, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            out = open(os.path.join(tmp, "out.txt"), "rb").read().decode("latin-1")
+            # argv[0] as the program saw it
+            out = out.replace(exe, "pcramp")
+            runs.append({"argv": argv, "seed": int(sp["args"][sp["args"].index("--seed") + 1]), "json": int("--o.json" in sp["args"]),
+                         "targets": [[d, len(q)] for d, q in targets], "backgrounds": [[d, len(q)] for d, q in bgs], "output": out})
+    return {"oligos": oligos, "runs": runs}
+
+
 def main():
     build_reference()
     ref = Reference()
@@ -515,7 +576,7 @@ def main():
                      ("thermo", thermo_golden), ("moves", moves_golden), ("sampler", sampler_golden),
                      ("overlap", overlap_golden), ("multiplex", multiplex_golden),
                      ("multiplex_optimize", multiplex_optimize_golden), ("amplicons", amplicons_golden),
-                     ("background", background_golden), ("multiplex_match", multiplex_match_golden)):
+                     ("background", background_golden), ("multiplex_match", multiplex_match_golden), ("writers", writers_golden)):
         if only and name not in only:
             continue
         with open(os.path.join(OUT, name + ".json"), "w") as f:

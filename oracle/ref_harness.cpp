@@ -867,6 +867,29 @@ float ref_oligo_overlap(const uint64_t assay[4], const uint64_t *pool, unsigned 
 	return p.compute_oligo_overlap(q);
 }
 
+// PCR::write / PCR::write_json (assay.h:288-375), all four forms: with_pool = 0 selects the pool-less overloads.
+// Returns the length of the text; at most cap bytes are stored.
+long ref_format_oligos(const uint64_t assay[4], const uint64_t *pool, unsigned n_pool, int json, int with_pool, char *out, long cap)
+{
+	try{
+		PCR p;
+		p.oligo( FORWARD, word_from(assay) );
+		p.oligo( REVERSE, word_from(assay + 2) );
+		deque<PCR> q(n_pool);
+		for(unsigned i = 0;i < n_pool;++i){
+			q[i].oligo( FORWARD, word_from(pool + 4*i) );
+			q[i].oligo( REVERSE, word_from(pool + 4*i + 2) );
+		}
+		ostringstream ss;
+		if(json){ if(with_pool) p.write_json(ss, q); else p.write_json(ss); }
+		else{ if(with_pool) p.write(ss, q); else p.write(ss); }
+		const string t = ss.str();
+		for(long i = 0;i < cap && i < (long)t.size();++i) out[i] = t[i];
+		return (long)t.size();
+	}
+	catch(...){ return -1; }
+}
+
 // PCR::collect_unique_amplicons (pcr_assay.cpp:756-813) over the session's DB: bounds in discovery order, the
 // unique amplicon Sequences as nibbles back to back.
 long ref_session_collect_amplicons(RefSession *s, const uint64_t pair[4], float threshold, int amp_min, int amp_max,

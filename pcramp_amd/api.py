@@ -75,6 +75,19 @@ class ThermoResult(C.Structure):
                 ("hairpin_tm", C.c_float), ("homodimer_tm", C.c_float), ("dG", C.c_float)]
 
 
+class Output(C.Structure):
+    _fields_ = [("json", C.c_int32), ("use_multiplex", C.c_int32), ("n_target", C.c_uint32), ("n_background", C.c_uint32),
+                ("target_deflines", C.POINTER(C.c_char_p)), ("background_deflines", C.POINTER(C.c_char_p)),
+                ("target_lengths", C.c_void_p), ("background_lengths", C.c_void_p)]
+
+
+class AssayRecord(C.Structure):
+    _fields_ = [("major_id", C.c_uint32), ("minor_id", C.c_uint32), ("assay", C.c_uint64 * 4),
+                ("target_coverage", C.c_float), ("background_coverage", C.c_float),
+                ("active_target_norm", C.c_float), ("active_background_norm", C.c_float),
+                ("num_active_background", C.c_uint32), ("target_match", C.c_void_p), ("background_match", C.c_void_p)]
+
+
 class AmplifyArgs(C.Structure):
     _fields_ = [("collect_threshold", C.c_float), ("ident_threshold", C.c_float), ("amp_min", C.c_int32),
                 ("amp_max", C.c_int32), ("use_taq_mama", C.c_int32)]
@@ -97,6 +110,7 @@ ABI_SYMBOLS = [
     "pcr_thermo", "pcr_dimer", "pcr_multiplex_compatible",
     "pcr_random_assays", "pcr_host_rand_r", "pcr_host_max_overlap", "pcr_host_oligo_overlap", "pcr_host_pool_overlaps",
     "pcr_multiplex_load", "pcr_multiplex_coverage", "pcr_collect_amplicons",
+    "pcr_format_oligos", "pcr_format_header", "pcr_format_iteration", "pcr_format_assay", "pcr_format_footer",
 ]
 
 
@@ -175,6 +189,13 @@ def load_library():
     L.pcr_host_move_trials.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_uint64]
     L.pcr_host_orientation_seeds.restype = C.c_int64
     L.pcr_host_orientation_seeds.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+    for fn in ("pcr_format_oligos", "pcr_format_header", "pcr_format_iteration", "pcr_format_assay", "pcr_format_footer"):
+        getattr(L, fn).restype = C.c_int64
+    L.pcr_format_oligos.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_char_p, C.c_uint64]
+    L.pcr_format_header.argtypes = [C.POINTER(Output), C.c_int, C.POINTER(C.c_char_p), C.c_uint32, C.c_char_p, C.c_uint64]
+    L.pcr_format_iteration.argtypes = [C.POINTER(Output), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_char_p, C.c_uint64]
+    L.pcr_format_assay.argtypes = [C.POINTER(Output), C.POINTER(AssayRecord), C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint64]
+    L.pcr_format_footer.argtypes = [C.POINTER(Output), C.c_void_p, C.c_void_p, C.c_char_p, C.c_uint64]
     _LIB = L
     return L
 
@@ -298,6 +319,80 @@ def bits_to_bool(words, n):
     w = np.ascontiguousarray(words, dtype=np.uint64)
     b = np.unpackbits(w.view(np.uint8), bitorder="little")
     return b[:n].astype(bool)
+
+
+# ---------------------------------------------------------------------------- assay-list writers (host only)
+def bool_to_bits(flags):
+    """bool[n] -> u64 BitSet words (bit i%64 of word i//64)."""
+    f = np.asarray(flags).astype(np.uint8)
+    pad = (-f.size) % 64
+    return np.packbits(np.concatenate([f, np.zeros(pad, np.uint8)]), bitorder="little").view(np.uint64).copy()
+
+
+class AssayWriter:
+    """The reference's output file, piece by piece (main.cpp:131-163, 440-519, 950-1264; assay.h:288-375).
+    Every method returns the bytes the reference writes at that point."""
+
+    def __init__(self, target_deflines, target_lengths, background_deflines=(), background_lengths=(), json=False,
+                 use_multiplex=True):
+        self.L = load_library()
+        self._keep = []
+        self.nt, self.nb = len(target_deflines), len(background_deflines)
+
+        def strs(v):
+            a = (C.c_char_p * max(len(v), 1))(*[x.encode() for x in v])
+            self._keep.append(a)
+            return C.cast(a, C.POINTER(C.c_char_p))
+
+        def lens(v):
+            a = np.ascontiguousarray(list(v) or [0], dtype=np.uint64)
+            self._keep.append(a)
+            return a.ctypes.data
+        self.o = Output(int(json), int(use_multiplex), self.nt, self.nb, strs(target_deflines), strs(background_deflines),
+                        lens(target_lengths), lens(background_lengths))
+
+    def _call(self, fn, *args):
+        n = fn(*args, None, 0)
+        if n < 0:
+            raise PcrError(_err(self.L))
+        buf = C.create_string_buffer(int(n) + 1)
+        fn(*args, buf, n + 1)
+        return buf.raw[:n]
+
+    def header(self, argv, seed):
+        a = (C.c_char_p * len(argv))(*[x.encode() for x in argv])
+        return self._call(self.L.pcr_format_header, C.byref(self.o), len(argv), a, int(seed))
+
+    def iteration(self, assay_iteration, major_id, minor_id, targets_remaining):
+        return self._call(self.L.pcr_format_iteration, C.byref(self.o), assay_iteration, major_id, minor_id, targets_remaining)
+
+    def assay(self, pair, major_id, minor_id, target_coverage, background_coverage, active_target_norm, active_background_norm,
+              num_active_background, target_match, background_match, pool=()):
+        tm, bm = bool_to_bits(target_match), bool_to_bits(background_match) if self.nb else None
+        r = AssayRecord(major_id, minor_id, (C.c_uint64 * 4)(pair[0][0], pair[0][1], pair[1][0], pair[1][1]), target_coverage,
+                        background_coverage, active_target_norm, active_background_norm, num_active_background,
+                        tm.ctypes.data, bm.ctypes.data if bm is not None else None)
+        p = W.pairs_array(list(pool)) if len(pool) else None
+        return self._call(self.L.pcr_format_assay, C.byref(self.o), C.byref(r), p.ctypes.data if p is not None else None, len(pool))
+
+    def footer(self, target_active, total_background):
+        a = np.ascontiguousarray(np.asarray(target_active).astype(np.uint8))
+        b = bool_to_bits(total_background) if self.nb else None
+        return self._call(self.L.pcr_format_footer, C.byref(self.o), a.ctypes.data, b.ctypes.data if b is not None else None)
+
+
+def format_oligos(pair, pool=(), json=False, use_multiplex=True):
+    """PCR::write / PCR::write_json (assay.h:288-375) -> bytes."""
+    L = load_library()
+    a = W.pairs_array([pair])
+    p = W.pairs_array(list(pool)) if len(pool) else None
+    args = (a.ctypes.data, p.ctypes.data if p is not None else None, len(pool), int(json), int(use_multiplex))
+    n = L.pcr_format_oligos(*args, None, 0)
+    if n < 0:
+        raise PcrError(_err(L))
+    buf = C.create_string_buffer(int(n) + 1)
+    L.pcr_format_oligos(*args, buf, n + 1)
+    return buf.raw[:n]
 
 
 # ---------------------------------------------------------------------------- the device handle

@@ -2022,3 +2022,4 @@ int64_t pcr_host_move_trials(const pcr_word128 *oligo, int move, double max_dege
 } // extern "C"
 
 #include "pcr_entry_sw_thermo.inc"
+#include "pcr_writers.inc"

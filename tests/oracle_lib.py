@@ -155,6 +155,18 @@ class _Lib:
         p = pairs_array(pool) if len(pool) else np.zeros((1, 4), dtype=np.uint64)
         return fn(a.ctypes.data, p.ctypes.data, len(pool))
 
+    def format_oligos(self, assay, pool=(), json=False, with_pool=True):
+        """Reference only: PCR::write / write_json (assay.h:288-375) -> bytes."""
+        fn = self.lib.ref_format_oligos
+        fn.restype = C.c_long
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_int, C.c_int, C.c_char_p, C.c_long]
+        a = pairs_array([assay])
+        p = pairs_array(list(pool)) if len(pool) else np.zeros((1, 4), dtype=np.uint64)
+        buf = C.create_string_buffer(4096)
+        n = fn(a.ctypes.data, p.ctypes.data, len(pool), int(json), int(with_pool), buf, 4096)
+        assert 0 <= n <= 4096
+        return buf.raw[:n]
+
     def taq_mama(self, p1, p2, t1, t2):
         return self._f("taq_mama")(p1, p2, t1, t2)
 
