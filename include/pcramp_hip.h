@@ -165,6 +165,13 @@ uint64_t pcr_bitset_words(pcr_ctx *ctx, pcr_set which);   /* ceil(n/64) */
  * pcr_profile_read: total milliseconds and number of bracketed launches since the last reset. */
 int pcr_profile_enable(pcr_ctx *ctx, int on);
 int pcr_profile_read(pcr_ctx *ctx, double *scan_ms, uint64_t *scan_launches, int reset);
+/* The same for the other kernels bench.py prices: while profiling is on, EVERY launch of the Smith-Waterman kernel
+ * (k_sw) and of the thermodynamics kernels is bracketed by HIP events on the handle's stream. */
+#define PCR_PROF_SCAN    0   /* = pcr_profile_read */
+#define PCR_PROF_SW      1
+#define PCR_PROF_THERMO  2
+#define PCR_PROF_KERNELS 3
+int pcr_profile_read_kernel(pcr_ctx *ctx, int kernel, double *ms, uint64_t *launches, int reset);
 
 /* Blocks until the handle's stream is idle. */
 int pcr_synchronize(pcr_ctx *ctx);

@@ -103,7 +103,7 @@ _LIB = None
 ABI_SYMBOLS = [
     "pcr_last_error", "pcr_create", "pcr_destroy", "pcr_load_sequences", "pcr_set_active", "pcr_split",
     "pcr_select_words", "pcr_get_entries", "pcr_amplify", "pcr_amplify_device", "pcr_screen_device", "pcr_move_coverage", "pcr_coverage_from_bits",
-    "pcr_weighted_coverage", "pcr_num_sequences", "pcr_bitset_words", "pcr_profile_enable", "pcr_profile_read",
+    "pcr_weighted_coverage", "pcr_num_sequences", "pcr_bitset_words", "pcr_profile_enable", "pcr_profile_read", "pcr_profile_read_kernel",
     "pcr_synchronize", "pcr_host_irregular_words", "pcr_host_window_valid", "pcr_host_candidates",
     "pcr_host_orientation_seeds", "pcr_host_move_trials",
     "pcr_sw_align_words", "pcr_background_match", "pcr_multiplex_match",
@@ -156,6 +156,7 @@ def load_library():
     L.pcr_bitset_words.argtypes = [C.c_void_p, C.c_int]
     L.pcr_profile_enable.argtypes = [C.c_void_p, C.c_int]
     L.pcr_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
+    L.pcr_profile_read_kernel.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
     L.pcr_synchronize.argtypes = [C.c_void_p]
     L.pcr_sw_align_words.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     L.pcr_background_match.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.POINTER(BackgroundArgs), C.c_void_p]
@@ -671,6 +672,13 @@ class Screener:
         ms = C.c_double(0.0)
         n = C.c_uint64(0)
         self._check(self.L.pcr_profile_read(self.h, C.byref(ms), C.byref(n), int(reset)))
+        return ms.value, n.value
+
+    def profile_read_kernel(self, kernel, reset=True):
+        """kernel: 0 = match scan, 1 = Smith-Waterman, 2 = thermodynamics -> (ms, launches) since the last reset."""
+        ms = C.c_double(0.0)
+        n = C.c_uint64(0)
+        self._check(self.L.pcr_profile_read_kernel(self.h, int(kernel), C.byref(ms), C.byref(n), int(reset)))
         return ms.value, n.value
 
     def synchronize(self):

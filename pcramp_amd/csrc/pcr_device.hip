@@ -529,6 +529,7 @@ __global__ __launch_bounds__(FINBIG_THREADS) void k_finalize_big(const Hit *__re
 
 // ============================================================================== host state
 constexpr uint32_t N_TOUCHED_UNKNOWN = 0xFFFFFFFFu;
+constexpr uint32_t EPOCH_LIMIT = (1u << 24) - 1;    // largest pass epoch that fits the 24-bit tag of best[]
 
 template<class T> struct DevBuf {
 	T *p = nullptr; size_t cap = 0;
@@ -612,6 +613,7 @@ struct pcr_ctx {
 	DevBuf<uint64_t> fin_scratch;   // k_finalize_big's keys
 	std::vector<uint16_t> seed_count; std::vector<uint8_t> seed_fill, seed_own;   // host scratch of the seed-table builder
 	uint32_t epoch = 0;         // pass counter tagging best[] (see HitSink)
+	uint32_t debug_epoch = 0;   // PCRAMP_DEBUG_EPOCH: value the counter takes when best[] is first cleared
 	uint64_t best_seen = 0;      // generation of best[] that has been cleared (the allocator may hand the same address back: never compare pointers)
 	// pinned staging for the small per-call host->device payload (candidates, tables, oligos): one async copy
 	// ring of host-mapped staging buffers: a slot is rewritten only after the k_stage that read it has run,
@@ -646,11 +648,31 @@ struct pcr_ctx {
 	bool prof = false; uint32_t prof_stride = 1, prof_pass = 0;   // events bracket the scan of every prof_stride-th pass
 	std::vector<std::pair<hipEvent_t, hipEvent_t> > prof_events;
 	double prof_ms = 0.0; uint64_t prof_launches = 0;
+	// the same for the other kernels bench.py prices (PCR_PROF_SW, PCR_PROF_THERMO): every launch while profiling is on
+	std::vector<std::pair<hipEvent_t, hipEvent_t> > prof_events_k[PCR_PROF_KERNELS];
+	double prof_ms_k[PCR_PROF_KERNELS] = {0.0, 0.0, 0.0}; uint64_t prof_launches_k[PCR_PROF_KERNELS] = {0, 0, 0};
 };
 
 namespace {
 
 int drain(pcr_ctx *ctx);
+
+// HIP events around one kernel launch of a priced kernel (PCR_PROF_*), on the launch stream, while profiling is on
+struct ProfScope {
+	pcr_ctx *ctx; int k; hipEvent_t e0 = nullptr, e1 = nullptr;
+	ProfScope(pcr_ctx *c, int kernel) : ctx(c), k(kernel)
+	{
+		if(!ctx->prof || k <= 0 || k >= PCR_PROF_KERNELS) return;
+		if(hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess){ if(e0) (void)hipEventDestroy(e0); e0 = e1 = nullptr; return; }
+		(void)hipEventRecord(e0, ctx->stream);
+	}
+	~ProfScope()
+	{
+		if(!e0) return;
+		(void)hipEventRecord(e1, ctx->stream);
+		ctx->prof_events_k[k].push_back(std::make_pair(e0, e1));
+	}
+};
 #define DRAIN(ctx) do{ if(!(ctx)->pending.empty()){ const int drc_ = drain(ctx); if(drc_ != PCR_OK) return drc_; } }while(0)
 
 struct HostTimer {
@@ -1094,6 +1116,7 @@ pcr_ctx *pcr_create(int device, void *hip_stream, const pcr_params *params)
 	else{ ctx->params.pack_max_degen = 256; ctx->params.pack_min_gc = 0.0f; ctx->params.pack_max_gc = 1.0f; }
 	{ hipDeviceProp_t prop; if(hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->n_cu = (uint32_t)prop.multiProcessorCount; }
 	if(const char *v = getenv("PCRAMP_TIMING")) ctx->timing = v[0] == '1';
+	if(const char *v = getenv("PCRAMP_DEBUG_EPOCH")) ctx->debug_epoch = (uint32_t)strtoul(v, nullptr, 0);   // test hook: start the pass counter near its wrap
 	if(const char *v = getenv("PCRAMP_SCAN")){ if(v[0] == '1') ctx->scan_version = 1; else if(v[0] == '2') ctx->scan_version = 2; }   // A/B: 1 = popcount scan, 2 = bit-sliced only
 	ctx->filt.max_degen = ctx->params.pack_max_degen;
 	ctx->filt.set_gc(ctx->params.pack_min_gc, ctx->params.pack_max_gc);
@@ -1129,6 +1152,7 @@ void pcr_destroy(pcr_ctx *ctx)
 			ctx->t_host[0]/n, ctx->t_host[1]/n, ctx->t_host[2]/n, ctx->t_host[3]/n, ctx->t_host[4]/n, ctx->t_host[5]/n, (unsigned long long)ctx->n_timed);
 	}
 	for(auto &pr : ctx->prof_events){ (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+	for(int k = 0;k < PCR_PROF_KERNELS;++k){ for(auto &pr : ctx->prof_events_k[k]){ (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); } }
 	for(int s = 0;s < 2;++s) ctx->sets[s].release();
 	ctx->best.release();
 	ctx->counters.release(); ctx->mask.release(); ctx->status.release(); ctx->hits.release();
@@ -1164,6 +1188,9 @@ int pcr_load_sequences(pcr_ctx *ctx, pcr_set which, const uint8_t *packed4, cons
 	DRAIN(ctx);
 	if(n >= (1u << 24)){ g_err = "pcr_load_sequences: at most 2^24-1 sequences per GPU shard"; return PCR_ERR_CAPACITY; }
 	HIP_TRY(hipSetDevice(ctx->device));
+	// a pass publishes its mailbox before its last kernel has finished (k_post publishes at its start): the blocking
+	// copies below go through the null stream, which a caller-supplied non-blocking stream does not order against
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
 	SeqSet &S = ctx->sets[which];
 	S.have_db = false; S.n_entries = 0; S.have_codes = false;
 	S.n = n;
@@ -1288,6 +1315,7 @@ int pcr_set_active(pcr_ctx *ctx, pcr_set which, const uint8_t *active)
 {
 	if(!ctx || !active){ g_err = "pcr_set_active: bad argument"; return PCR_ERR_ARG; }
 	DRAIN(ctx);
+	HIP_TRY(hipSetDevice(ctx->device));
 	SeqSet &S = ctx->sets[which];
 	for(uint32_t i = 0;i < S.n;++i) S.active[i] = active[i] ? 1 : 0;
 	if(S.n){
@@ -1301,6 +1329,8 @@ int pcr_split(pcr_ctx *ctx, pcr_set which, uint32_t seq, uint64_t pos)
 {
 	if(!ctx){ g_err = "null ctx"; return PCR_ERR_ARG; }
 	DRAIN(ctx);
+	HIP_TRY(hipSetDevice(ctx->device));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));        // the null-stream copies below must not overlap a pass still reading planes / has_eos
 	SeqSet &S = ctx->sets[which];
 	if(seq >= S.n || pos >= S.len[seq]){ g_err = "pcr_split: out of range"; return PCR_ERR_ARG; }
 	uint8_t &v = S.packed[seq][pos >> 1];
@@ -1359,10 +1389,10 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 	}
 	int rc;
 	if((rc = ctx->best.ensure((size_t)S.n*ncand)) != PCR_OK) return rc;
-	if(ctx->best.generation != ctx->best_seen || ctx->epoch >= (1u << 24) - 2){
-		// fresh (uninitialised) storage or epoch wrap: clear once; afterwards the epoch tag makes clearing unnecessary
+	if(ctx->best.generation != ctx->best_seen){
+		// fresh (uninitialised) storage: clear once; afterwards the epoch tag makes clearing unnecessary
 		HIP_TRY(hipMemsetAsync(ctx->best.p, 0, ctx->best.cap*sizeof(uint32_t), ctx->stream));
-		ctx->best_seen = ctx->best.generation; ctx->epoch = 0;
+		ctx->best_seen = ctx->best.generation; ctx->epoch = std::min(ctx->debug_epoch, EPOCH_LIMIT);
 	}
 	// ---- scan plan.  version 3 (default): orientations that can be seeded go through the pigeonhole seed
 	// scan; the others, and every tile holding IUPAC target codes, through the bit-sliced counter.
@@ -1565,6 +1595,12 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 		if((rc = ctx->hits.ensure(n_slots)) != PCR_OK) return rc;
 		if((rc = S.db.ensure(n_slots)) != PCR_OK) return rc;
 		if(attempt > 0) HIP_TRY(hipMemsetAsync(S.ctrl.p, 0, (8 + 2*(size_t)S.n)*sizeof(uint32_t), ctx->stream));
+		if(ctx->epoch >= EPOCH_LIMIT){
+			// the tag (epoch << 8 | count) is about to leave its 24 bits: every stale entry would compare HIGHER than the new
+			// pass's hits and swallow them.  Checked per attempt (every bucket-growth retry takes an epoch of its own).
+			HIP_TRY(hipMemsetAsync(ctx->best.p, 0, ctx->best.cap*sizeof(uint32_t), ctx->stream));
+			ctx->epoch = 0;
+		}
 		++ctx->epoch;
 		HitSink sink; sink.best = ctx->best.p; sink.hits = ctx->hits.p; sink.seq_count = d_seq_count;
 		sink.counters = d_counters; sink.cap = cap; sink.ncand = ncand; sink.epoch = ctx->epoch;
@@ -1926,6 +1962,24 @@ int pcr_profile_read(pcr_ctx *ctx, double *scan_ms, uint64_t *scan_launches, int
 	if(scan_ms) *scan_ms = ctx->prof_ms;
 	if(scan_launches) *scan_launches = ctx->prof_launches;
 	if(reset){ ctx->prof_ms = 0.0; ctx->prof_launches = 0; }
+	return PCR_OK;
+}
+
+int pcr_profile_read_kernel(pcr_ctx *ctx, int kernel, double *ms, uint64_t *launches, int reset)
+{
+	if(!ctx || kernel < 0 || kernel >= PCR_PROF_KERNELS){ g_err = "pcr_profile_read_kernel: bad argument"; return PCR_ERR_ARG; }
+	if(kernel == PCR_PROF_SCAN) return pcr_profile_read(ctx, ms, launches, reset);
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	for(auto &pr : ctx->prof_events_k[kernel]){
+		float t = 0.0f;
+		HIP_TRY(hipEventElapsedTime(&t, pr.first, pr.second));
+		ctx->prof_ms_k[kernel] += t; ctx->prof_launches_k[kernel] += 1;
+		(void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second);
+	}
+	ctx->prof_events_k[kernel].clear();
+	if(ms) *ms = ctx->prof_ms_k[kernel];
+	if(launches) *launches = ctx->prof_launches_k[kernel];
+	if(reset){ ctx->prof_ms_k[kernel] = 0.0; ctx->prof_launches_k[kernel] = 0; }
 	return PCR_OK;
 }
 

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 CSV output (gpurun_out/<run>/...) into the small summaries kept under profiles/.
 
-  python profiles/summarize.py stats gpurun_out/r01_stats  > profiles/r01_kernel_stats.md
-  python profiles/summarize.py pmc   gpurun_out/r01_fetch gpurun_out/r01_write > profiles/r01_hbm_traffic.md
+  python profiles/summarize.py stats gpurun_out/r02_stats  > profiles/r02_kernel_stats.md
+  python profiles/summarize.py pmc   profiles/r02_hbm_traffic.json gpurun_out/r02_fetch gpurun_out/r02_write > profiles/r02_hbm_traffic.md
+  python profiles/summarize.py sq    profiles/r02_valu_pmc.json gpurun_out/r02_sq > profiles/r02_valu_pmc.md
 """
 import collections
 import csv
@@ -59,9 +60,29 @@ def pmc(dirs):
     return out
 
 
+def sq(dirs):
+    """SQ counters per launch (averaged over the launches of a kernel): instruction counts are per WAVE instruction."""
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for d in dirs:
+        f = newest(d + "/*/*counter_collection.csv")
+        for r in csv.DictReader(open(f)):
+            agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    names = sorted({c for v in agg.values() for c in v})
+    print("| kernel | launches | " + " | ".join(names) + " |")
+    print("|---|---|" + "---|" * len(names))
+    out = {}
+    for k, v in sorted(agg.items()):
+        n = max(len(x) for x in v.values())
+        row = {c: (sum(v[c]) / len(v[c]) if v.get(c) else None) for c in names}
+        out[k] = dict(row, launches=n)
+        print("| %s | %d | " % (k, n) + " | ".join("%.4g" % row[c] if row[c] is not None else "-" for c in names) + " |")
+    return out
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2])
+    elif sys.argv[1] == "sq":
+        json.dump(sq(sys.argv[3:]), open(sys.argv[2], "w"), indent=1)
     else:
-        out = pmc(sys.argv[2:])
-        json.dump(out, open("profiles/r01_hbm_traffic.json", "w"), indent=1)
+        json.dump(pmc(sys.argv[3:]), open(sys.argv[2], "w"), indent=1)

@@ -261,6 +261,35 @@ def test_screen_device_replays_after_bucket_overflow(oracle):
         a.close()
 
 
+def test_epoch_wrap_with_bucket_growth_retries(oracle):
+    """best[] is tagged (pass epoch << 8 | count) and never cleared between passes.  A select that enters two passes
+    before the 24-bit epoch limit and needs bucket-growth retries (one epoch each) must clear the table when the
+    counter wraps instead of dropping every hit: same DB as the oracle before, across and after the wrap."""
+    rng = random.Random(12)
+    seqs = ["A" * 300 + rand_seq(rng, 300) + "AC" * 200 + rand_seq(rng, 100) + "T" * 300, rand_seq(rng, 1200)]
+    s1 = seqs[1]
+    txt = [("A" * 20, "A" * 20), ("AC" * 10, "GT" * 10), (s1[100:120], revcomp(s1[220:240]))]
+    pairs = [(oracle.centered_word(f), oracle.centered_word(r)) for f, r in txt]
+    thr = float(np.float32(1.0) * np.float32(0.9))
+    so = oracle.session()
+    for q in seqs:
+        so.add_target(q)
+    n_o = so.select(pairs)
+    want = so.db_entries()
+    os.environ["PCRAMP_DEBUG_EPOCH"] = str((1 << 24) - 3)
+    try:
+        a = _screener(None)
+    finally:
+        os.environ.pop("PCRAMP_DEBUG_EPOCH", None)
+    try:
+        for rep in range(4):
+            a.load_texts(seqs, [1.0, 1.0])               # resets the bucket size: every select retries with larger buckets
+            assert a.select_words(pairs, thr, 18) == n_o and n_o > 64, rep
+            assert a.entries() == want, rep
+    finally:
+        a.close()
+
+
 def test_screen_device_with_shift_candidates(oracle):
     """--optimize.5/--optimize.3 (every slot shift of every oligo is a candidate): many words per site, so the
     per-sequence buckets outgrow 64 slots and the one-launch tail runs in its 128- / 256-slot form.  The fused

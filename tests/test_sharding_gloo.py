@@ -77,6 +77,76 @@ def _worker(rank, world, port, tmp):
     dist.destroy_process_group()
 
 
+def _bench_worker(rank, world, port, tmp):
+    """The N>1 path of bench.py with its own helpers: a synth.GlobalSet cut by shard.shard_ranges, every rank screening
+    its block (the CPU oracle stands in for pcr_screen_device), the [world, K, 2, P, wmax] all-gather layout,
+    bench.assemble_gathered and bench.check_against_unsharded against the unsharded screen."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    from oracle_lib import Oracle
+    from pcramp_amd import shard, synth
+    orc = Oracle()
+    gs = synth.GlobalSet("C1", world, scale=1.3)               # world x 130 targets of 1 kb: blocks are not multiples of 64
+    pairs = gs.pairs()
+    ranges = shard.shard_ranges(gs.lengths, world)
+    lo, hi = ranges[rank]
+    wmax = max((b - a + 63) // 64 for a, b in ranges)
+    nb = (gs.L + 1) // 2
+
+    def screen(packed, n):
+        s = orc.session()
+        for i in range(n):
+            s.add_target_packed(packed[i * nb:(i + 1) * nb], gs.L)
+        s.select(pairs)
+        ori = [s.target_match(p, orient=True)[1] for p in pairs]
+        cov = np.array([s.target_coverage(p) for p in pairs], np.float32)
+        return np.stack([(o & 1) != 0 for o in ori]), np.stack([(o & 2) != 0 for o in ori]), cov
+    packed, _, _ = gs.members(lo, hi)
+    fr, rf, _ = screen(packed, hi - lo)
+    K = 2
+    local = torch.zeros((K, 2, len(pairs), wmax), dtype=torch.int64)
+    for k in range(len(pairs)):
+        local[0, 0, k, :(hi - lo + 63) // 64] = torch.from_numpy(pack_bits(fr[k]))
+        local[0, 1, k, :(hi - lo + 63) // 64] = torch.from_numpy(pack_bits(rf[k]))
+    gathered = torch.zeros((world, K, 2, len(pairs), wmax), dtype=torch.int64)
+    dist.all_gather_into_tensor(gathered.view(-1), local.view(-1))
+    full = bench.assemble_gathered(gathered[:, 0], ranges)
+    ok = True
+    if rank == 0:
+        upacked, _, _ = gs.members(0, gs.T)
+        ufr, urf, ucov = screen(upacked, gs.T)
+        try:
+            n_set = bench.check_against_unsharded(full, gs.T, list(range(gs.T)), ufr, urf, ucov)
+            ok = n_set > 0
+            # the sampled form (C4): first and last member of every block
+            ids = sorted(set([a for a, b in ranges if b > a] + [b - 1 for a, b in ranges if b > a]))
+            bench.check_against_unsharded(full, gs.T, ids, ufr[:, ids], urf[:, ids], None)
+            # and it does notice a wrong bit
+            bad = full.copy()
+            bad[0, 0, 0] ^= np.uint64(1)
+            try:
+                bench.check_against_unsharded(bad, gs.T, list(range(gs.T)), ufr, urf, ucov)
+                ok = False
+            except AssertionError:
+                pass
+        except AssertionError:
+            ok = False
+    with open(os.path.join(tmp, "ok%d" % rank), "w") as f:
+        f.write("1" if ok else "0")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_sharding_helpers(tmp_path, world):
+    port = 31500 + random.randint(0, 2000)
+    mp.spawn(_bench_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert open(os.path.join(str(tmp_path), "ok%d" % r)).read() == "1"
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_equals_unsharded(tmp_path, world):
     port = 29500 + random.randint(0, 2000)
