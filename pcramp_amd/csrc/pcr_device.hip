@@ -37,6 +37,7 @@
 #include <vector>
 #include <chrono>
 #include <algorithm>
+#include <unordered_map>
 
 #include "../../include/pcramp_hip.h"
 #include "pcr_host.hpp"
@@ -347,6 +348,7 @@ __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_AC
 
 #include "pcr_scan_bitsliced.inc"
 #include "pcr_scan_seed.inc"
+#include "pcr_scan_seed2.inc"
 
 // One workgroup per sequence: keep the hits that attain the final per-(sequence,candidate) maximum
 // (select_words.cpp:100-117), sort them by (loc, strand, kind, ord) (bitonic, LDS), drop duplicates
@@ -561,10 +563,12 @@ struct SeqSet {
 	DevBuf<uint4> planes;
 	DevBuf<uint32_t> valid, nib, tb, blk_seq, tile_seq, tile_pos0, irr_off, degen_tiles;
 	DevBuf<uint8_t> tile_degen; uint32_t n_degen_tiles = 0;
+	DevBuf<TileDesc> tile_desc;   // one per tile, with the sequence's active flag folded in (k_tile_desc; refreshed by pcr_set_active)
 	DevBuf<uint64_t> d_len, d_blk_off, d_nblk_real;
 	DevBuf<uint8_t> d_active;
 	std::vector<uint8_t> has_eos; DevBuf<uint8_t> d_has_eos;   // sequence holds an EOS nibble (record padding, splits): only then has_split has to look
 	DevBuf<IrrDev> irr;
+	DevBuf<IrrScan> irr_scan;     // the irregular words in scan order with their 2-bit codes (k_seed2)
 	DevBuf<uint8_t> codes; DevBuf<uint64_t> d_code_off; bool have_codes = false;
 	// word DB of the last select
 	bool have_db = false;
@@ -579,7 +583,7 @@ struct SeqSet {
 	uint32_t *d_seg_hi = nullptr;
 	void release()
 	{
-		irr_perm.release(); planes.release(); valid.release(); nib.release(); tb.release(); degen_tiles.release(); tile_degen.release(); blk_seq.release(); tile_seq.release(); tile_pos0.release();
+		tile_desc.release(); irr_scan.release(); irr_perm.release(); planes.release(); valid.release(); nib.release(); tb.release(); degen_tiles.release(); tile_degen.release(); blk_seq.release(); tile_seq.release(); tile_pos0.release();
 		irr_off.release(); d_len.release(); d_blk_off.release();
 		d_nblk_real.release(); d_active.release(); d_has_eos.release(); irr.release(); db.release(); touched.release(); ctrl.release(); codes.release(); d_code_off.release();
 	}
@@ -597,6 +601,15 @@ struct pcr_ctx {
 	// scratch
 	DevBuf<uint32_t> best, counters, mask, status;
 	int scan_version = 3;
+	bool force_seed1 = false;   // PCRAMP_SEED=1: the first form of the seed scan (A/B)
+	// second form of the seed scan: the pass's seed list, mask tables (reused between passes) and the per-oligo seed cache
+	std::vector<uint32_t> s2_seeds; std::vector<uint4> s2_masks; std::vector<uint8_t> s2_floors;
+	struct S2Key { uint32_t a, c, g, t, floor_; bool operator==(const S2Key &o) const { return a == o.a && c == o.c && g == o.g && t == o.t && floor_ == o.floor_; } };
+	struct S2KeyHash { size_t operator()(const S2Key &k) const { uint64_t h = 0x9E3779B97F4A7C15ull; for(uint32_t v : {k.a, k.c, k.g, k.t, k.floor_}){ h ^= v; h *= 0x100000001B3ull; h ^= h >> 29; } return (size_t)h; } };
+	struct S2Entry { std::vector<uint32_t> seeds; /* code << 14 | off << 9 */ uint32_t off_mask; bool seedable; };
+	std::unordered_map<S2Key, S2Entry, S2KeyHash> s2_cache;
+	std::vector<pcrhost::Seed> s2_tmp;
+	bool s2_attr_set = false; uint32_t s2_dbg = 0;
 	DevBuf<Hit> hits;
 	DevBuf<uint64_t> bits_fr, bits_rf;
 	DevBuf<OligoDev> oligos;
@@ -713,6 +726,20 @@ int upload_irregular(pcr_ctx *ctx, SeqSet &S)
 	for(int k = 0;k < 256;++k) S.irr_size_count[k] = 0;
 	for(const IrrDev &d : flat) ++S.irr_size_count[(d.meta >> 8) & 0xFF];
 	int rc;
+	{
+		std::vector<IrrScan> scan(perm.size());
+		for(size_t i = 0;i < perm.size();++i){
+			const IrrDev &d = flat[perm[i]];
+			const uint32_t multi = (d.w.a & d.w.c) | (d.w.a & d.w.g) | (d.w.a & d.w.t) | (d.w.c & d.w.g) | (d.w.c & d.w.t) | (d.w.g & d.w.t);
+			const uint32_t lo = d.w.c | d.w.t, hi = d.w.g | d.w.t;             // 2-bit code planes (A,C,G,T = 0..3; empty slots read as A)
+			uint64_t code = 0;
+			for(int k = 0;k < 32;++k) code |= ((uint64_t)(((lo >> k) & 1u) | (((hi >> k) & 1u) << 1))) << (2*k);
+			IrrScan r; r.w0 = (uint32_t)code; r.w1 = (uint32_t)(code >> 32); r.idx_flags = perm[i] | (multi ? 0x80000000u : 0u); r.seq = d.seq;
+			scan[i] = r;
+		}
+		if((rc = S.irr_scan.ensure(scan.size() + 1)) != PCR_OK) return rc;
+		if(!scan.empty()) HIP_TRY(hipMemcpy(S.irr_scan.p, scan.data(), scan.size()*sizeof(IrrScan), hipMemcpyHostToDevice));
+	}
 	if((rc = S.irr_perm.ensure(perm.size() + 1)) != PCR_OK) return rc;
 	if(!perm.empty()) HIP_TRY(hipMemcpyAsync(S.irr_perm.p, perm.data(), perm.size()*sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
 	if((rc = S.irr.ensure(flat.size())) != PCR_OK) return rc;
@@ -730,6 +757,17 @@ int run_valid(pcr_ctx *ctx, SeqSet &S, uint64_t first_block, uint64_t n_blocks)
 	const unsigned grid = (unsigned)((n_blocks + threads - 1)/threads);
 	hipLaunchKernelGGL(k_valid, dim3(grid), dim3(threads), 0, ctx->stream, S.planes.p, S.d_blk_off.p, S.blk_seq.p,
 		S.d_nblk_real.p, S.valid.p, S.total_blocks, ctx->filt.max_degen, ctx->filt.gc_ok, first_block, n_blocks);
+	HIP_TRY(hipGetLastError());
+	return PCR_OK;
+}
+
+int build_tile_desc(pcr_ctx *ctx, SeqSet &S)
+{
+	if(S.n_tiles == 0) return PCR_OK;
+	int rc = S.tile_desc.ensure(S.n_tiles);
+	if(rc != PCR_OK) return rc;
+	hipLaunchKernelGGL(k_tile_desc, dim3((S.n_tiles + 255)/256), dim3(256), 0, ctx->stream, S.d_blk_off.p, S.d_len.p, S.d_active.p, S.tile_seq.p,
+		S.tile_pos0.p, S.tile_degen.p, S.n_tiles, S.tile_desc.p);
 	HIP_TRY(hipGetLastError());
 	return PCR_OK;
 }
@@ -1117,6 +1155,8 @@ pcr_ctx *pcr_create(int device, void *hip_stream, const pcr_params *params)
 	{ hipDeviceProp_t prop; if(hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->n_cu = (uint32_t)prop.multiProcessorCount; }
 	if(const char *v = getenv("PCRAMP_TIMING")) ctx->timing = v[0] == '1';
 	if(const char *v = getenv("PCRAMP_DEBUG_EPOCH")) ctx->debug_epoch = (uint32_t)strtoul(v, nullptr, 0);   // test hook: start the pass counter near its wrap
+	if(const char *v = getenv("PCRAMP_SEED")) ctx->force_seed1 = v[0] == '1';
+	if(const char *v = getenv("PCRAMP_S2DBG")) ctx->s2_dbg = (uint32_t)atoi(v);
 	if(const char *v = getenv("PCRAMP_SCAN")){ if(v[0] == '1') ctx->scan_version = 1; else if(v[0] == '2') ctx->scan_version = 2; }   // A/B: 1 = popcount scan, 2 = bit-sliced only
 	ctx->filt.max_degen = ctx->params.pack_max_degen;
 	ctx->filt.set_gc(ctx->params.pack_min_gc, ctx->params.pack_max_gc);
@@ -1296,6 +1336,8 @@ int pcr_load_sequences(pcr_ctx *ctx, pcr_set which, const uint8_t *packed4, cons
 			S.d_nblk_real.p, S.tile_seq.p, S.tile_pos0.p, (uint32_t)n_tiles, S.tile_degen.p);
 		if(hipGetLastError() != hipSuccess){ g_err = "k_tile_degen launch failed"; return fail(PCR_ERR_DEVICE); }
 	}
+	if(total_blocks >= (uint64_t(1) << 40)){ g_err = "pcr_load_sequences: more than 2^40 blocks"; return fail(PCR_ERR_CAPACITY); }
+	if((rc = build_tile_desc(ctx, S)) != PCR_OK) return fail(rc);
 	if(hipStreamSynchronize(ctx->stream) != hipSuccess){ g_err = "load: stream sync failed"; return fail(PCR_ERR_DEVICE); }
 	if(n_tiles){
 		std::vector<uint8_t> flags(n_tiles);
@@ -1320,6 +1362,7 @@ int pcr_set_active(pcr_ctx *ctx, pcr_set which, const uint8_t *active)
 	for(uint32_t i = 0;i < S.n;++i) S.active[i] = active[i] ? 1 : 0;
 	if(S.n){
 		HIP_TRY(hipMemcpyAsync(S.d_active.p, S.active.data(), S.n, hipMemcpyHostToDevice, ctx->stream));
+		{ const int rc = build_tile_desc(ctx, S); if(rc != PCR_OK) return rc; }
 		HIP_TRY(hipStreamSynchronize(ctx->stream));
 	}
 	return PCR_OK;
@@ -1364,6 +1407,43 @@ int pcr_split(pcr_ctx *ctx, pcr_set which, uint32_t seq, uint64_t pos)
 
 namespace {
 
+inline uint32_t spread16(uint32_t v) { uint32_t r = 0; for(int i = 0;i < 16;++i) r |= ((v >> i) & 1u) << (2*i); return r; }
+
+// The seeds of a pass for the second form of the seed scan: per orientation from the cache (derived on a miss), listed as
+// code << 14 | slot offset << 9 | orientation.  false: more than S2_MAX_SEEDS seeds (the first form takes the pass).
+bool plan_seed2(pcr_ctx *ctx, const std::vector<pcrhost::Candidate> &cand, std::vector<uint32_t> &or_seed, std::vector<uint32_t> &or_plain, uint32_t &irr_off_mask)
+{
+	const uint32_t n_or = 2*(uint32_t)cand.size();
+	std::vector<uint32_t> &out = ctx->s2_seeds;
+	out.clear();
+	irr_off_mask = 0;
+	if(ctx->s2_cache.size() > 16384) ctx->s2_cache.clear();
+	for(uint32_t o = 0;o < n_or;++o){
+		const pcrhost::Candidate &c = cand[o >> 1];
+		const Planes &m = (o & 1u) ? c.rc : c.fwd;
+		const pcr_ctx::S2Key key = {m.a, m.c, m.g, m.t, c.floor_};
+		auto it = ctx->s2_cache.find(key);
+		if(it == ctx->s2_cache.end()){
+			pcr_ctx::S2Entry e; e.off_mask = 0;
+			ctx->s2_tmp.clear();
+			e.seedable = pcrhost::orientation_seeds(m, c.floor_, 0, ctx->s2_tmp, nullptr, S2_Q);
+			e.seeds.reserve(ctx->s2_tmp.size());
+			for(const pcrhost::Seed &sd : ctx->s2_tmp){ e.seeds.push_back((sd.code << 14) | ((uint32_t)sd.off << 9)); e.off_mask |= 1u << sd.off; }
+			it = ctx->s2_cache.emplace(key, std::move(e)).first;
+		}
+		const pcr_ctx::S2Entry &e = it->second;
+		if(!e.seedable){ or_plain.push_back(o); continue; }
+		or_seed.push_back(o);
+		if(out.size() + e.seeds.size() > S2_MAX_SEEDS) return false;
+		if(sizeof(S2Shared) + 32*(size_t)n_or + 6*(out.size() + e.seeds.size()) + 512 > 160*1024) return false;   // the tables of the pass must fit one CU's LDS
+		const size_t at = out.size();
+		out.resize(at + e.seeds.size());
+		for(size_t k = 0;k < e.seeds.size();++k) out[at + k] = e.seeds[k] | o;
+		if(!(o & 1u)) irr_off_mask |= e.off_mask;                       // slot offsets at which forward seeds sit (irregular-word scan)
+	}
+	return true;
+}
+
 // pcr_select_words proper.  async: enqueue one attempt and return without looking at the counters
 // (pcr_screen_device; the caller records the pass as pending).
 int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_pairs, int optimize_5, int optimize_3,
@@ -1403,7 +1483,16 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 	std::vector<std::vector<std::pair<uint16_t, int8_t> > > inheritors;   // per orientation: (shifted orientation, shift) sharing its seeds
 	size_t n_inherited = 0;
 	uint32_t irr_off_mask = 0;
-	if(ctx->scan_version == 3 && n_or <= 65535){
+	// The second form of the seed scan (pcr_scan_seed2.inc) takes the pass when no 5'/3' shift candidates are asked for and
+	// the orientations and their 9-gram seeds fit its LDS budget; the host then only LISTS the seeds (from a cache keyed by
+	// oligo and floor: between two optimiser iterations most oligos stay what they were).
+	bool use_seed2 = false;
+	if(ctx->scan_version == 3 && !ctx->force_seed1 && !optimize_5 && !optimize_3 && n_or <= S2_MAX_OR){
+		use_seed2 = plan_seed2(ctx, cand, or_seed, or_plain, irr_off_mask);
+		if(!use_seed2){ or_seed.clear(); or_plain.clear(); irr_off_mask = 0; }
+	}
+	if(use_seed2){ /* planned */ }
+	else if(ctx->scan_version == 3 && n_or <= 65535){
 		// a 5'/3' shift candidate inherits the seeds of the unshifted oligo, moved by its shift, as long as no
 		// padded 8-window would have to be clamped at the end of the word (it costs 1/10 of deriving them anew)
 		struct OrientInfo { uint32_t begin, end; int max_exact_pos; bool seeded; };
@@ -1432,8 +1521,9 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 	// code shared by more than 255 seeds, sends everything to the bit-sliced path.
 	std::vector<uint32_t> image, heads, multi;
 	SeedTables ST; memset(&ST, 0, sizeof(ST));
-	const size_t n_seeds = seeds.size() + n_inherited;
-	if(!or_seed.empty()){
+	Seed2Tables ST2; memset(&ST2, 0, sizeof(ST2));
+	const size_t n_seeds = use_seed2 ? ctx->s2_seeds.size() : seeds.size() + n_inherited;
+	if(!or_seed.empty() && !use_seed2){
 		image.assign(SEED_IMAGE_WORDS, 0u);
 		// count[] / own[] (one entry per 8-gram code) are kept all-zero between passes: only the entries a pass touched
 		// are cleared again (two 64K-entry memsets per pass were ~8 us of the host plan)
@@ -1537,6 +1627,18 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 		bytes += (tab_plain.tab.size() + tab_plain.bias.size() + or_plain.size() + 256)*sizeof(uint32_t);
 		bytes += (tab_seedset.tab.size() + tab_seedset.bias.size() + or_seed.size() + 256)*sizeof(uint32_t);
 		bytes += (image.size() + heads.size() + multi.size() + 64)*sizeof(uint32_t);
+		std::vector<uint4> &masks2 = ctx->s2_masks; std::vector<uint8_t> &floors2 = ctx->s2_floors;
+		if(use_seed2){
+			// per orientation: the four base-set planes spread to even bits (slot k -> bit 2k), slots 0..15 | 16..31
+			masks2.resize(2*(size_t)n_or); floors2.assign(((size_t)n_or + 15) & ~size_t(15), 0);
+			for(uint32_t o = 0;o < n_or;++o){
+				const Planes &m = (o & 1u) ? cand[o >> 1].rc : cand[o >> 1].fwd;
+				masks2[2*o] = make_uint4(spread16(m.a), spread16(m.c), spread16(m.g), spread16(m.t));
+				masks2[2*o + 1] = make_uint4(spread16(m.a >> 16), spread16(m.c >> 16), spread16(m.g >> 16), spread16(m.t >> 16));
+				floors2[o] = (uint8_t)std::min<uint32_t>(cand[o >> 1].floor_, 255u);
+			}
+			bytes += masks2.size()*sizeof(uint4) + floors2.size() + ctx->s2_seeds.size()*sizeof(uint32_t) + 512;
+		}
 		// fused pass: the amplicon screen's oligo table travels with the scan tables, its result bitsets are
 		// cleared by the same launch
 		std::vector<OligoDev> ol;
@@ -1570,6 +1672,12 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 			ST.image = st.put(image.data(), image.size());
 			ST.heads = st.put(heads.data(), heads.size());
 			ST.multi = multi.empty() ? ST.heads : st.put(multi.data(), multi.size());
+		}
+		if(use_seed2){
+			ST2.seeds = st.put(ctx->s2_seeds.data(), ctx->s2_seeds.size());
+			ST2.masks = st.put(masks2.data(), masks2.size());
+			ST2.floors = st.put(floors2.data(), floors2.size());
+			ST2.n_seeds = (uint32_t)ctx->s2_seeds.size(); ST2.n_or = n_or;
 		}
 		// the same launch clears the pass's control block (counters | per-sequence fills | segment ends)
 		if((rc = S.ctrl.ensure(8 + 2*(size_t)S.n + 4)) != PCR_OK) return rc;
@@ -1622,7 +1730,26 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 			}
 			else{
 				if(need_plain && (rc = launch_scan2(ctx, S, tab_plain, ncand, sink, d_tab_plain, d_bias_plain, nullptr, S.n_tiles, d_map_plain)) != PCR_OK) return rc;
-				if(!or_seed.empty()){
+				if(!or_seed.empty() && use_seed2){
+					const size_t dyn = 2*(size_t)n_or*sizeof(uint4) + (((size_t)n_or + 15) & ~size_t(15)) + 4*(size_t)ST2.n_seeds + 2*(((size_t)ST2.n_seeds + 1) & ~size_t(1)) + 16;
+					// persistent workgroups of 16 waves, one per CU (the tables they build take most of its LDS); the irregular words
+					// are taken by the same waves once their tiles are done
+					const uint32_t tiles_per_wg = S2_WAVES*2;
+					const dim3 sgrid(std::max<uint32_t>(1u, std::min<uint32_t>((S.n_tiles + tiles_per_wg - 1)/tiles_per_wg, ctx->n_cu))), sblock(S2_THREADS);
+					IrrArgs2 IA; IA.scan = S.irr_scan.p; IA.irr = S.irr.p; IA.n_live = n_live; IA.off_mask = or_plain.empty() ? irr_off_mask : 0u;
+					irr_fused = true;
+					if(getenv("PCRAMP_DEBUG")) fprintf(stderr, "[pcramp] k_seed2: %u workgroups, %u seeds, %zu + %zu B of LDS\n", sgrid.x, ST2.n_seeds, sizeof(S2Shared), dyn);
+					if(!ctx->s2_attr_set){
+						HIP_TRY(hipFuncSetAttribute((const void *)k_seed2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160*1024 - sizeof(S2Shared))));
+						ctx->s2_attr_set = true;
+					}
+					hipLaunchKernelGGL(k_seed2, sgrid, sblock, dyn, ctx->stream, S.tb.p, S.valid.p, S.tile_desc.p, S.n_tiles, ST2, S.d_active.p, ctx->d_cand_fwd, ctx->d_cand_floor, ncand, IA, sink,
+						ctx->s2_dbg);
+					HIP_TRY(hipGetLastError());
+					if(need_seedset && (rc = launch_scan2(ctx, S, tab_seedset, ncand, sink, d_tab_seedset, d_bias_seedset, S.degen_tiles.p,
+						S.n_degen_tiles, d_map_seedset)) != PCR_OK) return rc;
+				}
+				else if(!or_seed.empty()){
 					const bool cand_lds = ncand <= SEED_CAND_LDS;   // (candidates read from global to fit 8 workgroups per CU: 140 vs 102 us)
 					const size_t dyn = cand_lds ? (size_t)ncand*(2*sizeof(uint4) + sizeof(uint32_t)) : 0;
 					// persistent workgroups: exactly as many as are resident at once (a partial second round would

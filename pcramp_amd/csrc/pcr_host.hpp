@@ -519,22 +519,22 @@ inline double planes_degeneracy(const Planes &w)
 //          when q < 8 the 8-window is padded with don't-care positions (all 4 bases enumerated);
 //   t = 1, 8 slots: those codes plus the ones with exactly one position outside its base set
 //          (25 codes for a plain 8-mer).
-// The scan looks the TARGET's 8-gram up at every position and evaluates exactly only the windows a
+// The scan looks the TARGET's 8-gram (9-gram in its second form) up at every position and evaluates exactly only the windows a
 // hit implies.  Among the admissible (number of t=1 blocks, number of t=0 blocks) the cheapest is
 // taken, cost = expected hits per target position = codes / 4^8.  A target 8-gram holding an IUPAC
 // code can match seeds it is not equal to, so tiles containing such bases are scanned by the
 // bit-sliced kernel instead (pcr_device.hip); so are orientations for which no structure exists
 // (low thresholds: blocks shorter than 5) or whose IUPAC slots expand too far.
-struct Seed { uint32_t code; uint16_t orient; uint8_t q; uint8_t off; };   // q = 8 always; orient = 2*candidate + {0: fwd, 1: rc}; off = slot of the 8-window's first base
+struct Seed { uint32_t code; uint16_t orient; uint8_t q; uint8_t off; };   // q = gram length (8, or 9 for the second form of the seed scan); orient = 2*candidate + {0: fwd, 1: rc}; off = slot of the window's first base
 
-enum { SEED_Q = 8, MIN_SEED_BLOCK = 5, MAX_SEED_CODES = 512 /* per orientation */ };
+enum { SEED_Q = 8, SEED_Q_MAX = 9, MIN_SEED_BLOCK = 5, MAX_SEED_CODES = 512 /* per orientation */ };
 
 // all codes whose position j lies in sets[j] (4-bit base sets, bit 0 = A ... bit 3 = T; first base in the LOW bits)
-inline void seed_emit(const unsigned sets[SEED_Q], uint32_t orient, uint32_t off, std::vector<Seed> &out)
+inline void seed_emit(const unsigned *sets, int Q, uint32_t orient, uint32_t off, std::vector<Seed> &out)
 {
 	uint32_t fixed = 0; unsigned total = 1;
-	int nf = 0, fpos[SEED_Q]; unsigned nd[SEED_Q]; uint8_t base[SEED_Q][4];
-	for(int j = 0;j < SEED_Q;++j){
+	int nf = 0, fpos[SEED_Q_MAX]; unsigned nd[SEED_Q_MAX]; uint8_t base[SEED_Q_MAX][4];
+	for(int j = 0;j < Q;++j){
 		const unsigned st = sets[j];
 		if(st == 0) return;
 		if((st & (st - 1)) == 0){ fixed |= (uint32_t)__builtin_ctz(st) << (2*j); continue; }
@@ -545,7 +545,7 @@ inline void seed_emit(const unsigned sets[SEED_Q], uint32_t orient, uint32_t off
 	const size_t at = out.size();
 	out.resize(at + total);
 	Seed *dst = out.data() + at;
-	Seed sd; sd.orient = (uint16_t)orient; sd.q = SEED_Q; sd.off = (uint8_t)off;
+	Seed sd; sd.orient = (uint16_t)orient; sd.q = (uint8_t)Q; sd.off = (uint8_t)off;
 	for(unsigned idx = 0;idx < total;++idx){
 		uint32_t code = fixed; unsigned r = idx;
 		for(int f = 0;f < nf;++f){ code |= (uint32_t)base[f][r % nd[f]] << (2*fpos[f]); r /= nd[f]; }
@@ -554,17 +554,19 @@ inline void seed_emit(const unsigned sets[SEED_Q], uint32_t orient, uint32_t off
 	}
 }
 
-inline unsigned seed_count(const unsigned sets[SEED_Q])
+inline unsigned seed_count(const unsigned *sets, int Q)
 {
 	unsigned n = 1;
-	for(int j = 0;j < SEED_Q;++j) n *= (unsigned)__builtin_popcount(sets[j]);
+	for(int j = 0;j < Q;++j) n *= (unsigned)__builtin_popcount(sets[j]);
 	return n;
 }
 
 // Appends the seeds of one orientation; returns false (nothing appended) if it cannot be seeded.
-// max_exact_pos (optional): largest first slot of a budget-0 block (-1 if none); while it stays <= 24 under a
+// max_exact_pos (optional): largest first slot of a budget-0 block (-1 if none); while it stays <= 32 - Q under a
 // slot shift of the oligo the seeds of the shifted oligo are these seeds with `off` moved by the shift.
-inline bool orientation_seeds(const Planes &m, uint32_t floor_, uint32_t orient, std::vector<Seed> &out, int *max_exact_pos = nullptr)
+// Q: gram length (8 bases = 16-bit codes, the first form of the scan; 9 = 18-bit codes, the second form: three times fewer
+// false seed hits per target position for the same oligo, since the code space grows faster than the code lists).
+inline bool orientation_seeds(const Planes &m, uint32_t floor_, uint32_t orient, std::vector<Seed> &out, int *max_exact_pos = nullptr, int Q = SEED_Q)
 {
 	if(max_exact_pos) *max_exact_pos = -1;
 	const uint32_t occ = m.a | m.c | m.g | m.t;
@@ -579,26 +581,26 @@ inline bool orientation_seeds(const Planes &m, uint32_t floor_, uint32_t orient,
 	for(int j = first + size;j < 32;++j) slot_set[j] = 0;
 	const bool plain = ((m.a & m.c) | (m.a & m.g) | (m.a & m.t) | (m.c & m.g) | (m.c & m.t) | (m.g & m.t)) == 0;   // no IUPAC slot: code counts are known
 
-	// the structures: n1 blocks with budget 1 (8 slots each, at the 3' end of the occupied range) and
+	// the structures: n1 blocks with budget 1 (Q slots each, at the 3' end of the occupied range) and
 	// n0 = k + 1 - 2*n1 blocks with budget 0 sharing the rest as evenly as possible
 	int best_n1 = -1; double best_cost = 1e30; unsigned best_codes = 0;
 	for(int n1 = 0;2*n1 <= k + 1;++n1){
 		const int n0 = k + 1 - 2*n1;
-		const int rest = size - SEED_Q*n1;
+		const int rest = size - Q*n1;
 		if(rest < 0 || (n0 > 0 && rest/n0 < MIN_SEED_BLOCK)) continue;
 		if(n0 == 0 && n1 == 0) continue;
 		unsigned codes = 0; bool ok = true;
 		int pos = first;
 		for(int b = 0;b < n0 && ok;++b){
 			const int len = rest/n0 + ((b < rest % n0) ? 1 : 0);
-			const int q = std::min<int>(len, SEED_Q);
-			const int ws = std::min(pos, 32 - SEED_Q);                    // 8-window holding the block's first q slots
+			const int q = std::min<int>(len, Q);
+			const int ws = std::min(pos, 32 - Q);                         // Q-window holding the block's first q slots
 			unsigned c;
-			if(plain) c = 1u << (2*(SEED_Q - q));
+			if(plain) c = 1u << (2*(Q - q));
 			else{
-				unsigned sets[SEED_Q];
-				for(int j = 0;j < SEED_Q;++j){ const int sl = ws + j; sets[j] = (sl >= pos && sl < pos + q) ? slot_set[sl] : 15u; }
-				c = seed_count(sets);
+				unsigned sets[SEED_Q_MAX];
+				for(int j = 0;j < Q;++j){ const int sl = ws + j; sets[j] = (sl >= pos && sl < pos + q) ? slot_set[sl] : 15u; }
+				c = seed_count(sets, Q);
 			}
 			if(c > MAX_SEED_CODES) ok = false;
 			codes += c;
@@ -606,20 +608,20 @@ inline bool orientation_seeds(const Planes &m, uint32_t floor_, uint32_t orient,
 		}
 		for(int b = 0;b < n1 && ok;++b){
 			unsigned c;
-			if(plain) c = 1 + 3*SEED_Q;
+			if(plain) c = 1 + 3*Q;
 			else{
-				unsigned sets[SEED_Q];
-				for(int j = 0;j < SEED_Q;++j) sets[j] = slot_set[pos + j];
-				c = seed_count(sets);
+				unsigned sets[SEED_Q_MAX];
+				for(int j = 0;j < Q;++j) sets[j] = slot_set[pos + j];
+				c = seed_count(sets, Q);
 				const unsigned all = c;
-				for(int j = 0;j < SEED_Q;++j){
+				for(int j = 0;j < Q;++j){
 					const unsigned dj = (unsigned)__builtin_popcount(sets[j]);
 					if(dj < 4) c += all/dj*(4 - dj);
 				}
 			}
 			if(c > MAX_SEED_CODES) ok = false;
 			codes += c;
-			pos += SEED_Q;
+			pos += Q;
 		}
 		if(!ok || codes > MAX_SEED_CODES) continue;
 		const double cost = (double)codes;
@@ -627,29 +629,29 @@ inline bool orientation_seeds(const Planes &m, uint32_t floor_, uint32_t orient,
 	}
 	if(best_n1 < 0) return false;
 	(void)best_codes;
-	const int n1 = best_n1, n0 = k + 1 - 2*n1, rest = size - SEED_Q*n1;
+	const int n1 = best_n1, n0 = k + 1 - 2*n1, rest = size - Q*n1;
 	int pos = first;
 	for(int b = 0;b < n0;++b){
 		const int len = rest/n0 + ((b < rest % n0) ? 1 : 0);
-		const int q = std::min<int>(len, SEED_Q);
-		const int ws = std::min(pos, 32 - SEED_Q);
-		unsigned sets[SEED_Q];
-		for(int j = 0;j < SEED_Q;++j){ const int sl = ws + j; sets[j] = (sl >= pos && sl < pos + q) ? slot_set[sl] : 15u; }
-		seed_emit(sets, orient, (uint32_t)ws, out);
+		const int q = std::min<int>(len, Q);
+		const int ws = std::min(pos, 32 - Q);
+		unsigned sets[SEED_Q_MAX];
+		for(int j = 0;j < Q;++j){ const int sl = ws + j; sets[j] = (sl >= pos && sl < pos + q) ? slot_set[sl] : 15u; }
+		seed_emit(sets, Q, orient, (uint32_t)ws, out);
 		if(max_exact_pos) *max_exact_pos = std::max(*max_exact_pos, pos);
 		pos += len;
 	}
 	for(int b = 0;b < n1;++b){
-		unsigned sets[SEED_Q];
-		for(int j = 0;j < SEED_Q;++j) sets[j] = slot_set[pos + j];
-		seed_emit(sets, orient, (uint32_t)pos, out);                       // no mismatch in the window
-		for(int j = 0;j < SEED_Q;++j){                                      // exactly one, at position j
+		unsigned sets[SEED_Q_MAX];
+		for(int j = 0;j < Q;++j) sets[j] = slot_set[pos + j];
+		seed_emit(sets, Q, orient, (uint32_t)pos, out);                    // no mismatch in the window
+		for(int j = 0;j < Q;++j){                                          // exactly one, at position j
 			const unsigned keep = sets[j];
 			sets[j] = ~keep & 15u;
-			if(sets[j]) seed_emit(sets, orient, (uint32_t)pos, out);
+			if(sets[j]) seed_emit(sets, Q, orient, (uint32_t)pos, out);
 			sets[j] = keep;
 		}
-		pos += SEED_Q;
+		pos += Q;
 	}
 	return true;
 }
