@@ -216,8 +216,7 @@ struct HitSink { uint32_t *best; Hit *hits; uint32_t *seq_count; uint32_t *count
 // all on one address -- more than the whole seed scan).
 // best[] holds (pass epoch << 8) | count, so it never needs clearing: values of earlier passes compare lower.
 
-// (by value: a reference would make every kernel spill its HitSink to scratch at entry -- 64 B per lane of HBM writes)
-__device__ __noinline__ void record_hit(const HitSink k, uint32_t seq, uint32_t cand, uint64_t key, uint32_t cnt)
+__device__ __forceinline__ void record_hit_inline(const HitSink &k, uint32_t seq, uint32_t cand, uint64_t key, uint32_t cnt)
 {
 	const uint32_t tagged = (k.epoch << 8) | cnt;
 	const uint32_t old = atomicMax(&k.best[(size_t)seq*k.ncand + cand], tagged);
@@ -229,6 +228,12 @@ __device__ __noinline__ void record_hit(const HitSink k, uint32_t seq, uint32_t 
 		}
 		else{ atomicOr(&k.counters[0], 1u); atomicMax(&k.counters[2], slot + 1); }
 	}
+}
+
+// (by value: a reference would make every kernel spill its HitSink to scratch at entry -- 64 B per lane of HBM writes)
+__device__ __noinline__ void record_hit(const HitSink k, uint32_t seq, uint32_t cand, uint64_t key, uint32_t cnt)
+{
+	record_hit_inline(k, seq, cand, key, cnt);
 }
 
 __device__ __forceinline__ uint64_t make_key(uint32_t seq, int32_t loc, uint32_t strand /*1|2*/, uint32_t kind, uint32_t ord)
@@ -616,8 +621,9 @@ struct pcr_ctx {
 	DevBuf<SwJob> sw_jobs; DevBuf<SwOut> sw_out; DevBuf<uint8_t> sw_q, sw_qlen, sw_t, entry_codes, entry_lens;
 	DevBuf<AmpRec> amp_recs, amp_recs2; DevBuf<BgPairDev> bg_pairs;
 	DevBuf<uint64_t> amp_keys; DevBuf<uint32_t> amp_pkeys, amp_pair_start; DevBuf<uint8_t> sort_tmp;   // reference-order sort of the candidate amplicons (order_amplicons)
-	DevBuf<thermo::Job> th_jobs; DevBuf<thermo::JobOut> th_out; DevBuf<int> th_dg, th_scratch_i; DevBuf<unsigned short> th_scratch_s;
+	DevBuf<thermo::Job> th_jobs; DevBuf<thermo::JobOut> th_out; DevBuf<int> th_dg;
 	float th_dg_salt = -1.0f;   // salt the table in th_dg was built for
+	uint8_t *sw_pin = nullptr, *sw_pin_dev = nullptr; hipEvent_t sw_done[2] = {nullptr, nullptr};   // pcr_sw_align_words: two pinned chunk buffers (words in, results out)
 	DevBuf<pcr_amplicon> mx_amp;   // pcr_collect_amplicons records
 	DevBuf<Planes> mx_keys; uint32_t mx_n_keys = 0; DevBuf<uint32_t> mx_count;   // multiplex background: unique words of the accepted amplicons (pcr_multiplex.inc)
 	size_t amp_cap = size_t(1) << 20;
@@ -1202,7 +1208,9 @@ void pcr_destroy(pcr_ctx *ctx)
 	if(ctx->ret_host) (void)hipHostFree(ctx->ret_host);
 	if(ctx->in_host) (void)hipHostFree(ctx->in_host);
 	if(ctx->ret_flag) (void)hipHostFree(ctx->ret_flag);
-	ctx->oligos.release(); ctx->sw_jobs.release(); ctx->sw_out.release(); ctx->sw_q.release(); ctx->sw_qlen.release(); ctx->sw_t.release(); ctx->entry_codes.release(); ctx->entry_lens.release(); ctx->amp_recs.release(); ctx->amp_recs2.release(); ctx->amp_keys.release(); ctx->amp_pkeys.release(); ctx->amp_pair_start.release(); ctx->sort_tmp.release(); ctx->bg_pairs.release(); ctx->th_jobs.release(); ctx->th_out.release(); ctx->th_dg.release(); ctx->th_scratch_i.release(); ctx->th_scratch_s.release(); ctx->mx_keys.release(); ctx->mx_count.release(); ctx->mx_amp.release();
+	if(ctx->sw_pin) (void)hipHostFree(ctx->sw_pin);
+	for(int k = 0;k < 2;++k){ if(ctx->sw_done[k]) (void)hipEventDestroy(ctx->sw_done[k]); }
+	ctx->oligos.release(); ctx->sw_jobs.release(); ctx->sw_out.release(); ctx->sw_q.release(); ctx->sw_qlen.release(); ctx->sw_t.release(); ctx->entry_codes.release(); ctx->entry_lens.release(); ctx->amp_recs.release(); ctx->amp_recs2.release(); ctx->amp_keys.release(); ctx->amp_pkeys.release(); ctx->amp_pair_start.release(); ctx->sort_tmp.release(); ctx->bg_pairs.release(); ctx->th_jobs.release(); ctx->th_out.release(); ctx->th_dg.release(); ctx->mx_keys.release(); ctx->mx_count.release(); ctx->mx_amp.release();
 	if(ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 }

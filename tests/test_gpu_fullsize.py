@@ -13,19 +13,23 @@ from pcramp_amd import api, synth
 pytestmark = pytest.mark.gpu
 
 
-def _screener(scan=None):
-    old = os.environ.get("PCRAMP_SCAN")
-    if scan is None:
-        os.environ.pop("PCRAMP_SCAN", None)
-    else:
-        os.environ["PCRAMP_SCAN"] = str(scan)
+def _screener(scan=None, seed_form=None):
+    """scan: PCRAMP_SCAN (2 = bit-sliced scan for everything); seed_form=1: the first form of the seed scan (k_seed)
+    instead of the second (k_seed2)."""
+    old = {k: os.environ.get(k) for k in ("PCRAMP_SCAN", "PCRAMP_SEED")}
+    for k, v in (("PCRAMP_SCAN", scan), ("PCRAMP_SEED", seed_form)):
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = str(v)
     try:
         return api.Screener(0)
     finally:
-        if old is None:
-            os.environ.pop("PCRAMP_SCAN", None)
-        else:
-            os.environ["PCRAMP_SCAN"] = old
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 @pytest.fixture(scope="module")
@@ -45,13 +49,19 @@ def _screen(d, wl, lo=0, hi=None, thr_t=1.0, mult=0.9):
 
 def test_full_c2_properties(c2):
     import torch
-    a, b = _screener(None), _screener(2)
+    a, b, s1 = _screener(None), _screener(2), _screener(None, seed_form=1)
     try:
         n3, fr3, rf3, cov3 = _screen(a, c2)
         n2, fr2, rf2, cov2 = _screen(b, c2)
         # seed scan == bit-sliced scan at full size
         assert n3 == n2 and n3 > 1000
         assert np.array_equal(fr3, fr2) and np.array_equal(rf3, rf2) and np.array_equal(cov3, cov2)
+        # second form of the seed scan (9-gram seeds, tables built in LDS) == first form (8-gram seeds, host-built tables),
+        # word DB entry for entry
+        n1, fr1, rf1, cov1 = _screen(s1, c2)
+        assert n1 == n3 and np.array_equal(fr1, fr3) and np.array_equal(rf1, rf3)
+        assert s1.entries() == a.entries()
+        s1.close()
         assert fr3.any() or rf3.any()
         # idempotence
         n3b, fr3b, rf3b, cov3b = _screen(a, c2)
@@ -77,6 +87,7 @@ def test_full_c2_properties(c2):
     finally:
         a.close()
         b.close()
+        s1.close()
 
 
 def test_megabase_sequences_and_table_overflow():
