@@ -339,6 +339,42 @@ float pcr_host_oligo_overlap(const pcr_pair *assay, const pcr_pair *pool, uint32
 /* glibc rand_r (the reference's random source, sample.cpp:12), restated; usable without a GPU. */
 uint32_t pcr_host_rand_r(uint32_t *seed);
 
+/* ---- The local search behind the ABI, batched over trial assays (scope row f-1) */
+
+/* The `Options` fields optimize() and its moves read (pcramp.h:83-128). */
+typedef struct {
+	double  max_degen;               /* opt.degen */
+	int32_t primer_min, primer_max;  /* opt.primer_range */
+	pcr_thermo_args thermo;          /* is_valid of the trial oligos: salt, primer_strand, tm range, max_hairpin (no dimer test there) */
+	pcr_amplify_args target;         /* collect_threshold = target_threshold*target_search_multiplier, ident_threshold = target_threshold,
+	                                    target amplicon range, use_taq_mama (optimize.cpp:61-77) */
+	pcr_amplify_args background;     /* the same with the background thresholds and amplicon range */
+	int32_t have_background;         /* 0: no background sequences, background coverage is 0 */
+	int32_t use_multiplex;           /* opt.use_multiplex: multiplex background coverage (pcr_multiplex_load) and oligo reuse join the Score */
+	float   multiplex_threshold;     /* opt.background_threshold, the threshold of the multiplex background coverage */
+	int32_t n_moves;                 /* optimization_moves (main.cpp:82-95), at most 8, in order: PCR_MOVE_* */
+	int32_t moves[8];
+} pcr_optimize_args;
+
+/* optimize() (optimize.cpp:14-207) for n assays at once -- the body of the parallel loop main.cpp:697-887 runs for every
+ * trial assay of a design iteration.  The word DBs of the target set (and of the background set if have_background) must
+ * have been built for these assays (pcr_select_words), as main.cpp builds them before it optimises.  All assays advance
+ * in lockstep; per optimiser iteration ONE thermodynamics launch decides is_valid for every trial word of every assay
+ * and ONE move-coverage pass per sequence set evaluates them (see pcr_optimize.inc).  pool = the assays designed so
+ * far (use_multiplex).
+ *   best_out[i]      : the best assay found for assays[i] (oligos centred as optimize.cpp:152 leaves them)
+ *   score_out[3*i..] : its Score {target_coverage, background_coverage, oligo_overlap} (pcramp.h:158-208); optional
+ *   iterations_out[i]: optimiser iterations it took; optional */
+int pcr_optimize_batch(pcr_ctx *ctx, const pcr_pair *assays, uint32_t n, const pcr_optimize_args *args, const pcr_pair *pool, uint32_t n_pool,
+	pcr_pair *best_out, float *score_out, uint32_t *iterations_out);
+
+/* optimization_move (optimize.cpp:303-352): ONE move (PCR_MOVE_*) of ONE oligo (side 0 = F, 1 = R) of one assay.
+ * score_threshold (3 floats, optional): the Score trials are measured against; NULL = the unmodified assay's own Score,
+ * as optimization_move computes it.  word_out = the winning trial word (not re-centred; all zero if no trial survives),
+ * score_out = its Score (Score() = {-1e6, 1e6, 0} then), base_score_out (optional) = the unmodified assay's Score. */
+int pcr_optimization_move(pcr_ctx *ctx, const pcr_pair *assay, int move, int side, const pcr_optimize_args *args, const pcr_pair *pool, uint32_t n_pool,
+	const float *score_threshold, pcr_word128 *word_out, float *score_out, float *base_score_out);
+
 /* ---- Assay-list writers (scope row f-4): the bytes `pcramp` writes to its output file.  Host only. */
 
 /* What the writers read besides the assay itself (Options::output_format, opt.use_multiplex, the sequence records). */

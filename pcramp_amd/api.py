@@ -111,6 +111,7 @@ ABI_SYMBOLS = [
     "pcr_random_assays", "pcr_host_rand_r", "pcr_host_max_overlap", "pcr_host_oligo_overlap", "pcr_host_pool_overlaps",
     "pcr_multiplex_load", "pcr_multiplex_coverage", "pcr_collect_amplicons",
     "pcr_format_oligos", "pcr_format_header", "pcr_format_iteration", "pcr_format_assay", "pcr_format_footer",
+    "pcr_optimize_batch", "pcr_optimization_move",
 ]
 
 

@@ -559,7 +559,7 @@ struct SeqSet {
 	uint32_t n = 0;
 	std::vector<std::vector<uint8_t> > packed;   // host copy (split_sequence, irregular re-derivation)
 	std::vector<uint64_t> len, blk_off, nblk_real;
-	std::vector<float> weight;
+	std::vector<float> weight; DevBuf<float> d_weight; bool weight_dirty = true;   // device copy on demand (pcr_optimize_batch)
 	std::vector<uint8_t> active;
 	std::vector<std::vector<pcrhost::IrrEntry> > irr_host;
 	uint64_t total_blocks = 0;
@@ -588,7 +588,7 @@ struct SeqSet {
 	uint32_t *d_seg_hi = nullptr;
 	void release()
 	{
-		tile_desc.release(); irr_scan.release(); irr_perm.release(); planes.release(); valid.release(); nib.release(); tb.release(); degen_tiles.release(); tile_degen.release(); blk_seq.release(); tile_seq.release(); tile_pos0.release();
+		d_weight.release(); tile_desc.release(); irr_scan.release(); irr_perm.release(); planes.release(); valid.release(); nib.release(); tb.release(); degen_tiles.release(); tile_degen.release(); blk_seq.release(); tile_seq.release(); tile_pos0.release();
 		irr_off.release(); d_len.release(); d_blk_off.release();
 		d_nblk_real.release(); d_active.release(); d_has_eos.release(); irr.release(); db.release(); touched.release(); ctrl.release(); codes.release(); d_code_off.release();
 	}
@@ -625,6 +625,7 @@ struct pcr_ctx {
 	float th_dg_salt = -1.0f;   // salt the table in th_dg was built for
 	uint8_t *sw_pin = nullptr, *sw_pin_dev = nullptr; hipEvent_t sw_done[2] = {nullptr, nullptr};   // pcr_sw_align_words: two pinned chunk buffers (words in, results out)
 	DevBuf<pcr_amplicon> mx_amp;   // pcr_collect_amplicons records
+	DevBuf<OligoDev> opt_oligos; DevBuf<uint2> opt_jobs; DevBuf<float> opt_cov;   // pcr_optimize_batch: base oligos + trial words, per-oligo variant ranges, coverages
 	DevBuf<Planes> mx_keys; uint32_t mx_n_keys = 0; DevBuf<uint32_t> mx_count;   // multiplex background: unique words of the accepted amplicons (pcr_multiplex.inc)
 	size_t amp_cap = size_t(1) << 20;
 	uint32_t n_cu = 256;        // compute units of the device (hipDeviceProp)
@@ -1210,7 +1211,7 @@ void pcr_destroy(pcr_ctx *ctx)
 	if(ctx->ret_flag) (void)hipHostFree(ctx->ret_flag);
 	if(ctx->sw_pin) (void)hipHostFree(ctx->sw_pin);
 	for(int k = 0;k < 2;++k){ if(ctx->sw_done[k]) (void)hipEventDestroy(ctx->sw_done[k]); }
-	ctx->oligos.release(); ctx->sw_jobs.release(); ctx->sw_out.release(); ctx->sw_q.release(); ctx->sw_qlen.release(); ctx->sw_t.release(); ctx->entry_codes.release(); ctx->entry_lens.release(); ctx->amp_recs.release(); ctx->amp_recs2.release(); ctx->amp_keys.release(); ctx->amp_pkeys.release(); ctx->amp_pair_start.release(); ctx->sort_tmp.release(); ctx->bg_pairs.release(); ctx->th_jobs.release(); ctx->th_out.release(); ctx->th_dg.release(); ctx->mx_keys.release(); ctx->mx_count.release(); ctx->mx_amp.release();
+	ctx->oligos.release(); ctx->sw_jobs.release(); ctx->sw_out.release(); ctx->sw_q.release(); ctx->sw_qlen.release(); ctx->sw_t.release(); ctx->entry_codes.release(); ctx->entry_lens.release(); ctx->amp_recs.release(); ctx->amp_recs2.release(); ctx->amp_keys.release(); ctx->amp_pkeys.release(); ctx->amp_pair_start.release(); ctx->sort_tmp.release(); ctx->bg_pairs.release(); ctx->th_jobs.release(); ctx->th_out.release(); ctx->th_dg.release(); ctx->mx_keys.release(); ctx->mx_count.release(); ctx->mx_amp.release(); ctx->opt_oligos.release(); ctx->opt_jobs.release(); ctx->opt_cov.release();
 	if(ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
@@ -1246,6 +1247,7 @@ int pcr_load_sequences(pcr_ctx *ctx, pcr_set which, const uint8_t *packed4, cons
 	S.len.assign(lengths, lengths + n);
 	S.weight.assign(n, 1.0f);
 	if(weights) S.weight.assign(weights, weights + n);
+	S.weight_dirty = true;
 	S.active.assign(n, 1);
 	S.has_eos.assign(n, 0);
 	S.blk_off.assign(n + 1, 0);

@@ -226,13 +226,21 @@ def test_optimize_loop_matches_oracle(oracle, case):
         d.select_words(pairs, thr, 18, True, True, which=api.TARGET)
         d.select_words(pairs, bthr, 16, True, True, which=api.BACKGROUND)
         changed = 0
+        want = []
         for p in pairs:
             po, so_ = oracle_optimize(oracle, to, bo, p, **case)
             pd, sd = moves.optimize(d, p, target_threshold=o["target_threshold"], use_taq_mama=bool(o["use_taq_mama"]), **case)
             assert pd == po
             assert tuple(float(x) for x in sd) == so_
             changed += po != p
+            want.append((po, so_))
         assert changed > 0
+        # the same assays as ONE batch (pcr_optimize_batch: lockstep iterations, one thermodynamics launch and one coverage
+        # pass per set and iteration for all of them) -- assays finish after different numbers of iterations
+        bp, bs, it = moves.optimize_batch(d, pairs * 3, target_threshold=o["target_threshold"], use_taq_mama=bool(o["use_taq_mama"]), **case)
+        for k in range(len(pairs) * 3):
+            assert bp[k] == want[k % len(pairs)][0] and tuple(float(x) for x in bs[k]) == want[k % len(pairs)][1], k
+        assert len(set(it)) > 1
     finally:
         d.close()
 
