@@ -417,7 +417,8 @@ inline void build_candidates(const uint64_t *pairs /* n x {F[2],R[2]} */, uint32
 // 64-bit blocks from the least significant nibble up); within a slot A -> C -> G -> T restricted
 // to the slot's base set.  Each expansion is returned as base indices 0..3 (A,C,G,T) of the
 // occupied slots start()..stop(), i.e. what Word::str() spells.
-inline bool expand_oligo(const Planes &w, std::vector<std::vector<uint8_t> > &out, size_t cap)
+template<class F>
+inline bool for_each_expansion(const Planes &w, size_t cap, F f /* (const uint8_t *bases, int len) */)
 {
 	int order[32];
 	for(int i = 0;i < 16;++i){ order[i] = 15 - i; order[16 + i] = 31 - i; }
@@ -425,14 +426,15 @@ inline bool expand_oligo(const Planes &w, std::vector<std::vector<uint8_t> > &ou
 	for(int k = 0;k < 32;++k){ set[k] = (uint8_t)planes_nibble(w, k); cur[k] = set[k] ? (uint8_t)(set[k] & (0u - set[k])) : 0; }
 	const int first = planes_start(w), last = planes_stop(w);
 	if(last < first) return true;
+	size_t n = 0;
+	uint8_t s[32];
 	while(true){
-		if(out.size() >= cap) return false;
-		std::vector<uint8_t> s;
+		if(n >= cap) return false;
 		for(int k = first;k <= last;++k){
 			const uint8_t c = cur[k];
-			s.push_back((c == 1) ? 0 : (c == 2) ? 1 : (c == 4) ? 2 : (c == 8) ? 3 : 255);   // EOS inside an oligo: illegal base
+			s[k - first] = (c == 1) ? 0 : (c == 2) ? 1 : (c == 4) ? 2 : (c == 8) ? 3 : 255;   // EOS inside an oligo: illegal base
 		}
-		out.push_back(s);
+		f(s, last - first + 1); ++n;
 		bool advanced = false;
 		for(int oi = 0;oi < 32 && !advanced;++oi){
 			const int k = order[oi];
@@ -449,6 +451,11 @@ inline bool expand_oligo(const Planes &w, std::vector<std::vector<uint8_t> > &ou
 		if(!advanced) break;
 	}
 	return true;
+}
+
+inline bool expand_oligo(const Planes &w, std::vector<std::vector<uint8_t> > &out, size_t cap)
+{
+	return for_each_expansion(w, cap > out.size() ? cap - out.size() : 0, [&out](const uint8_t *b, int len){ out.push_back(std::vector<uint8_t>(b, b + len)); });
 }
 
 // Word::max_overlap (word.h:38-91): the DP there gives a cell its diagonal predecessor's count plus one where
