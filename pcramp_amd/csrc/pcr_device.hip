@@ -615,6 +615,10 @@ struct pcr_ctx {
 	std::unordered_map<S2Key, S2Entry, S2KeyHash> s2_cache;
 	std::vector<pcrhost::Seed> s2_tmp;
 	bool s2_attr_set = false; uint32_t s2_dbg = 0;
+	// first form, tables built on the device (k_seed_tables): the pass's seed list, its own per-oligo cache (8-gram seeds), the tables
+	std::vector<uint32_t> s1_seeds; std::unordered_map<S2Key, S2Entry, S2KeyHash> s1_cache;
+	DevBuf<uint32_t> s1_image, s1_heads, s1_multi;
+	bool host_seed_tables = false;   // PCRAMP_SEED_TABLES=host: build them on the host as for passes with shift candidates (A/B)
 	DevBuf<Hit> hits;
 	DevBuf<uint64_t> bits_fr, bits_rf;
 	DevBuf<OligoDev> oligos;
@@ -1163,6 +1167,7 @@ pcr_ctx *pcr_create(int device, void *hip_stream, const pcr_params *params)
 	if(const char *v = getenv("PCRAMP_TIMING")) ctx->timing = v[0] == '1';
 	if(const char *v = getenv("PCRAMP_DEBUG_EPOCH")) ctx->debug_epoch = (uint32_t)strtoul(v, nullptr, 0);   // test hook: start the pass counter near its wrap
 	if(const char *v = getenv("PCRAMP_SEED")) ctx->force_seed1 = v[0] == '1';
+	if(const char *v = getenv("PCRAMP_SEED_TABLES")) ctx->host_seed_tables = v[0] == 'h';
 	if(const char *v = getenv("PCRAMP_S2DBG")) ctx->s2_dbg = (uint32_t)atoi(v);
 	if(const char *v = getenv("PCRAMP_SCAN")){ if(v[0] == '1') ctx->scan_version = 1; else if(v[0] == '2') ctx->scan_version = 2; }   // A/B: 1 = popcount scan, 2 = bit-sliced only
 	ctx->filt.max_degen = ctx->params.pack_max_degen;
@@ -1203,6 +1208,7 @@ void pcr_destroy(pcr_ctx *ctx)
 	for(int s = 0;s < 2;++s) ctx->sets[s].release();
 	ctx->best.release();
 	ctx->counters.release(); ctx->mask.release(); ctx->status.release(); ctx->hits.release();
+	ctx->s1_image.release(); ctx->s1_heads.release(); ctx->s1_multi.release();
 	ctx->bits_fr.release(); ctx->bits_rf.release(); ctx->arena.release(); ctx->fin_scratch.release();
 	for(auto &sl : ctx->stage){ if(sl.host) (void)hipHostFree(sl.host); if(sl.done) (void)hipEventDestroy(sl.done); }
 	if(ctx->mail) (void)hipHostFree(ctx->mail);
@@ -1454,6 +1460,54 @@ bool plan_seed2(pcr_ctx *ctx, const std::vector<pcrhost::Candidate> &cand, std::
 	return true;
 }
 
+// The seeds of a pass for the first form with device-built tables: per orientation from the cache (8-gram seeds), listed as
+// code | slot offset << 16 | orientation << 21.  When the lists exceed S1_MAX_SEEDS (low thresholds: hundreds of codes per
+// orientation) the orientations with the longest lists go to the bit-sliced scan.
+void plan_seed1(pcr_ctx *ctx, const std::vector<pcrhost::Candidate> &cand, std::vector<uint32_t> &or_seed, std::vector<uint32_t> &or_plain, uint32_t &irr_off_mask)
+{
+	const uint32_t n_or = 2*(uint32_t)cand.size();
+	std::vector<uint32_t> &out = ctx->s1_seeds;
+	out.clear();
+	irr_off_mask = 0;
+	if(ctx->s1_cache.size() > 16384) ctx->s1_cache.clear();
+	std::vector<const pcr_ctx::S2Entry *> ent(n_or);
+	size_t total = 0;
+	for(uint32_t o = 0;o < n_or;++o){
+		const pcrhost::Candidate &c = cand[o >> 1];
+		const Planes &m = (o & 1u) ? c.rc : c.fwd;
+		const pcr_ctx::S2Key key = {m.a, m.c, m.g, m.t, c.floor_};
+		auto it = ctx->s1_cache.find(key);
+		if(it == ctx->s1_cache.end()){
+			pcr_ctx::S2Entry e; e.off_mask = 0;
+			ctx->s2_tmp.clear();
+			e.seedable = pcrhost::orientation_seeds(m, c.floor_, 0, ctx->s2_tmp);
+			e.seeds.reserve(ctx->s2_tmp.size());
+			for(const pcrhost::Seed &sd : ctx->s2_tmp){ e.seeds.push_back(sd.code | ((uint32_t)sd.off << 16)); e.off_mask |= 1u << sd.off; }
+			it = ctx->s1_cache.emplace(key, std::move(e)).first;
+		}
+		ent[o] = &it->second;                                            // (unordered_map: references stay valid across insertions)
+		if(ent[o]->seedable) total += ent[o]->seeds.size();
+	}
+	std::vector<uint8_t> drop(n_or, 0);
+	if(total > S1_MAX_SEEDS){
+		std::vector<uint32_t> by_len;
+		for(uint32_t o = 0;o < n_or;++o){ if(ent[o]->seedable) by_len.push_back(o); }
+		std::stable_sort(by_len.begin(), by_len.end(), [&](uint32_t x, uint32_t y){ return ent[x]->seeds.size() > ent[y]->seeds.size(); });
+		for(size_t i = 0;i < by_len.size() && total > S1_MAX_SEEDS;++i){ drop[by_len[i]] = 1; total -= ent[by_len[i]]->seeds.size(); }
+	}
+	out.resize(total);
+	size_t at = 0;
+	for(uint32_t o = 0;o < n_or;++o){
+		const pcr_ctx::S2Entry &e = *ent[o];
+		if(!e.seedable || drop[o]){ or_plain.push_back(o); continue; }
+		or_seed.push_back(o);
+		const uint32_t tag = o << 21;
+		for(size_t k = 0;k < e.seeds.size();++k) out[at + k] = e.seeds[k] | tag;
+		at += e.seeds.size();
+		if(!(o & 1u)) irr_off_mask |= e.off_mask;                       // slot offsets at which forward seeds sit (irregular-word scan)
+	}
+}
+
 // pcr_select_words proper.  async: enqueue one attempt and return without looking at the counters
 // (pcr_screen_device; the caller records the pass as pending).
 int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_pairs, int optimize_5, int optimize_3,
@@ -1496,17 +1550,26 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 	// The second form of the seed scan (pcr_scan_seed2.inc) takes the pass when no 5'/3' shift candidates are asked for and
 	// the orientations and their 9-gram seeds fit its LDS budget; the host then only LISTS the seeds (from a cache keyed by
 	// oligo and floor: between two optimiser iterations most oligos stay what they were).
+	struct OrientInfo { uint32_t begin, end; int max_exact_pos; bool seeded; };
+	std::vector<OrientInfo> info;
 	bool use_seed2 = false;
 	if(ctx->scan_version == 3 && !ctx->force_seed1 && !optimize_5 && !optimize_3 && n_or <= S2_MAX_OR){
 		use_seed2 = plan_seed2(ctx, cand, or_seed, or_plain, irr_off_mask);
+		// an orientation without a 9-gram structure (low thresholds: k = 4 mismatching slots and more) may still have an 8-gram
+		// one: let the first form plan the pass, it hands fewer orientations to the bit-sliced scan
+		if(use_seed2 && !or_plain.empty()) use_seed2 = false;
 		if(!use_seed2){ or_seed.clear(); or_plain.clear(); irr_off_mask = 0; }
 	}
-	if(use_seed2){ /* planned */ }
+	bool dev_tables = false;                           // first form, tables built by k_seed_tables
+	if(!use_seed2 && ctx->scan_version == 3 && !ctx->host_seed_tables && !optimize_5 && !optimize_3 && n_or <= S1_MAX_OR){
+		plan_seed1(ctx, cand, or_seed, or_plain, irr_off_mask);
+		dev_tables = true;
+	}
+	if(use_seed2 || dev_tables){ /* planned */ }
 	else if(ctx->scan_version == 3 && n_or <= 65535){
 		// a 5'/3' shift candidate inherits the seeds of the unshifted oligo, moved by its shift, as long as no
 		// padded 8-window would have to be clamped at the end of the word (it costs 1/10 of deriving them anew)
-		struct OrientInfo { uint32_t begin, end; int max_exact_pos; bool seeded; };
-		std::vector<OrientInfo> info(n_or);
+		info.assign(n_or, OrientInfo());
 		inheritors.assign(n_or, std::vector<std::pair<uint16_t, int8_t> >());
 		seeds.reserve((size_t)n_or*32);
 		for(uint32_t o = 0;o < n_or;++o){
@@ -1532,9 +1595,8 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 	std::vector<uint32_t> image, heads, multi;
 	SeedTables ST; memset(&ST, 0, sizeof(ST));
 	Seed2Tables ST2; memset(&ST2, 0, sizeof(ST2));
-	const size_t n_seeds = use_seed2 ? ctx->s2_seeds.size() : seeds.size() + n_inherited;
-	if(!or_seed.empty() && !use_seed2){
-		image.assign(SEED_IMAGE_WORDS, 0u);
+	const size_t n_seeds = use_seed2 ? ctx->s2_seeds.size() : dev_tables ? ctx->s1_seeds.size() : seeds.size() + n_inherited;
+	if(!or_seed.empty() && !use_seed2 && !dev_tables){
 		// count[] / own[] (one entry per 8-gram code) are kept all-zero between passes: only the entries a pass touched
 		// are cleared again (two 64K-entry memsets per pass were ~8 us of the host plan)
 		if(ctx->seed_count.size() != 65536){ ctx->seed_count.assign(65536, 0); ctx->seed_own.assign(65536, 0); }
@@ -1542,19 +1604,43 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 		bool overflow = false;
 		uint32_t distinct = 0;
 		std::vector<uint8_t> &own = ctx->seed_own;                          // seeds listed under the code (its inheritors come on top)
+		for(;;){
+			image.assign(SEED_IMAGE_WORDS, 0u);
+			overflow = false; distinct = 0;
+			for(const pcrhost::Seed &sd : seeds){
+				uint16_t &c = count[sd.code];
+				if(c == 0){ image[sd.code >> 5] |= 1u << (sd.code & 31); ++distinct; }
+				c = (uint16_t)(c + 1 + (inheritors.empty() ? 0 : inheritors[sd.orient].size()));
+				if(c > 255){ overflow = true; break; }
+				++own[sd.code];
+			}
+			if(distinct > SEED_MAX_DISTINCT) overflow = true;
+			if(!overflow || n_inherited || or_seed.size() < 2) break;
+			// Too dense (low thresholds: hundreds of codes per orientation): hand the quarter of the seeded orientations
+			// with the longest code lists to the bit-sliced scan and count again.
+			for(const pcrhost::Seed &sd : seeds){ count[sd.code] = 0; own[sd.code] = 0; }
+			std::vector<uint32_t> by_len(or_seed);
+			std::stable_sort(by_len.begin(), by_len.end(), [&](uint32_t x, uint32_t y){ return info[x].end - info[x].begin > info[y].end - info[y].begin; });
+			const size_t n_drop = (by_len.size() + 3)/4;
+			std::vector<uint8_t> drop(n_or, 0);
+			for(size_t i = 0;i < n_drop;++i) drop[by_len[i]] = 1;
+			std::vector<pcrhost::Seed> kept; kept.reserve(seeds.size());
+			for(uint32_t o = 0;o < n_or;++o){
+				const uint32_t b = info[o].begin, e = info[o].end;
+				info[o].begin = (uint32_t)kept.size();
+				if(!drop[o]) kept.insert(kept.end(), seeds.begin() + b, seeds.begin() + e);
+				info[o].end = (uint32_t)kept.size();
+				if(drop[o]) info[o].seeded = false;
+			}
+			seeds.swap(kept);
+			or_seed.clear(); or_plain.clear();
+			for(uint32_t o = 0;o < n_or;++o){ if(info[o].seeded) or_seed.push_back(o); else or_plain.push_back(o); }
+		}
 		for(const pcrhost::Seed &sd : seeds){                                 // slot offsets at which forward seeds sit (irregular-word scan)
 			if(sd.orient & 1u) continue;
 			irr_off_mask |= 1u << sd.off;
 			if(!inheritors.empty()){ for(const std::pair<uint16_t, int8_t> &in : inheritors[sd.orient]) irr_off_mask |= 1u << (sd.off + in.second); }
 		}
-		for(const pcrhost::Seed &sd : seeds){
-			uint16_t &c = count[sd.code];
-			if(c == 0){ image[sd.code >> 5] |= 1u << (sd.code & 31); ++distinct; }
-			c = (uint16_t)(c + 1 + (inheritors.empty() ? 0 : inheritors[sd.orient].size()));
-			if(c > 255){ overflow = true; break; }
-			++own[sd.code];
-		}
-		if(distinct > SEED_MAX_DISTINCT) overflow = true;
 		if(overflow){
 			or_plain.clear(); or_seed.clear(); image.clear();
 			for(uint32_t o = 0;o < n_or;++o) or_plain.push_back(o);
@@ -1649,6 +1735,8 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 			}
 			bytes += masks2.size()*sizeof(uint4) + floors2.size() + ctx->s2_seeds.size()*sizeof(uint32_t) + 512;
 		}
+		const bool build_tables = dev_tables && !or_seed.empty();
+		if(build_tables) bytes += ctx->s1_seeds.size()*sizeof(uint32_t) + 256;
 		// fused pass: the amplicon screen's oligo table travels with the scan tables, its result bitsets are
 		// cleared by the same launch
 		std::vector<OligoDev> ol;
@@ -1683,6 +1771,14 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 			ST.heads = st.put(heads.data(), heads.size());
 			ST.multi = multi.empty() ? ST.heads : st.put(multi.data(), multi.size());
 		}
+		const uint32_t *d_s1_seeds = nullptr;
+		if(build_tables){
+			d_s1_seeds = st.put(ctx->s1_seeds.data(), ctx->s1_seeds.size());
+			if((rc = ctx->s1_image.ensure(SEED_IMAGE_WORDS)) != PCR_OK) return rc;
+			if((rc = ctx->s1_heads.ensure(S1_MAX_SEEDS)) != PCR_OK) return rc;
+			if((rc = ctx->s1_multi.ensure(S1_MAX_SEEDS)) != PCR_OK) return rc;
+			ST.image = ctx->s1_image.p; ST.heads = ctx->s1_heads.p; ST.multi = ctx->s1_multi.p; ST.flat = 1;
+		}
 		if(use_seed2){
 			ST2.seeds = st.put(ctx->s2_seeds.data(), ctx->s2_seeds.size());
 			ST2.masks = st.put(masks2.data(), masks2.size());
@@ -1697,6 +1793,11 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 			if((rc = st.ship(S.ctrl.p, (8 + 2*(size_t)S.n)*sizeof(uint32_t), fa->d_fr, bits_bytes, fa->d_rf, bits_bytes, ctx->mail_seq + 1)) != PCR_OK) return rc;
 		}
 		else if((rc = st.ship(S.ctrl.p, (8 + 2*(size_t)S.n)*sizeof(uint32_t), nullptr, 0, nullptr, 0, ctx->mail_seq + 1)) != PCR_OK) return rc;
+		if(build_tables){
+			hipLaunchKernelGGL(k_seed_tables, dim3(1), dim3(S1_BUILD_THREADS), 0, ctx->stream, d_s1_seeds, (uint32_t)ctx->s1_seeds.size(),
+				ctx->s1_image.p, ctx->s1_heads.p, ctx->s1_multi.p);
+			HIP_TRY(hipGetLastError());
+		}
 	}
 
 	timer.next(2);

@@ -517,21 +517,22 @@ inline double planes_degeneracy(const Planes &w)
 // Seeds for the match scan (generalised pigeonhole).
 //
 // An orientation with m occupied slots and floor f tolerates k = m - f mismatching slots.  Cut the
-// occupied slots into disjoint blocks and give block i a budget t_i in {0, 1} with
+// occupied slots into disjoint blocks and give block i a budget t_i in {0, 1, 2} with
 // sum(t_i + 1) >= k + 1: if every block had more than t_i mismatches the window would have at least
 // k + 1, so a window reaching the floor has SOME block with at most t_i mismatching slots.  The
 // same holds for any sub-window of a block.  Every block therefore yields a set of 8-gram codes
 // (2 bits per base) at a fixed slot offset:
 //   t = 0, block of q >= 5 slots: the codes whose block positions lie in the oligo's base sets;
 //          when q < 8 the 8-window is padded with don't-care positions (all 4 bases enumerated);
-//   t = 1, 8 slots: those codes plus the ones with exactly one position outside its base set
-//          (25 codes for a plain 8-mer).
+//   t = 1, 8 or 7 slots: those codes plus the ones with exactly one position outside its base set
+//          (25 codes for a plain 8-mer, 4 x 22 for a padded 7-mer);
+//   t = 2, 8 slots: plus the ones with exactly two positions outside (277 codes for a plain 8-mer).
 // The scan looks the TARGET's 8-gram (9-gram in its second form) up at every position and evaluates exactly only the windows a
-// hit implies.  Among the admissible (number of t=1 blocks, number of t=0 blocks) the cheapest is
+// hit implies.  Among the admissible block structures the cheapest is
 // taken, cost = expected hits per target position = codes / 4^8.  A target 8-gram holding an IUPAC
 // code can match seeds it is not equal to, so tiles containing such bases are scanned by the
 // bit-sliced kernel instead (pcr_device.hip); so are orientations for which no structure exists
-// (low thresholds: blocks shorter than 5) or whose IUPAC slots expand too far.
+// (more than MAX_SEED_CODES codes: very low thresholds, or IUPAC slots that expand too far).
 struct Seed { uint32_t code; uint16_t orient; uint8_t q; uint8_t off; };   // q = gram length (8, or 9 for the second form of the seed scan); orient = 2*candidate + {0: fwd, 1: rc}; off = slot of the window's first base
 
 enum { SEED_Q = 8, SEED_Q_MAX = 9, MIN_SEED_BLOCK = 5, MAX_SEED_CODES = 512 /* per orientation */ };
@@ -568,8 +569,64 @@ inline unsigned seed_count(const unsigned *sets, int Q)
 	return n;
 }
 
+// codes a block contributes: every window position inside its base set, or up to `budget` positions outside theirs
+// (don't-care positions, sets[j] = 15, have no outside)
+inline unsigned seed_block_codes(const unsigned *sets, int Q, int budget)
+{
+	const unsigned c0 = seed_count(sets, Q);
+	if(c0 == 0 || budget == 0) return c0;
+	unsigned d[SEED_Q_MAX];
+	for(int j = 0;j < Q;++j) d[j] = (unsigned)__builtin_popcount(sets[j]);
+	unsigned c = c0;
+	for(int j = 0;j < Q;++j){
+		if(d[j] == 4) continue;
+		const unsigned cj = c0/d[j]*(4 - d[j]);
+		c += cj;
+		if(budget >= 2){ for(int i = j + 1;i < Q;++i){ if(d[i] < 4) c += cj/d[i]*(4 - d[i]); } }
+	}
+	return c;
+}
+
+inline void seed_emit_block(unsigned *sets, int Q, uint32_t orient, uint32_t off, int budget, std::vector<Seed> &out)
+{
+	seed_emit(sets, Q, orient, off, out);                                  // no mismatch in the window
+	if(budget < 1) return;
+	for(int j = 0;j < Q;++j){                                              // exactly one, at position j
+		const unsigned keep = sets[j], outside = ~keep & 15u;
+		if(!outside) continue;
+		sets[j] = outside;
+		seed_emit(sets, Q, orient, off, out);
+		if(budget >= 2){                                                   // exactly two, at positions j < i
+			for(int i = j + 1;i < Q;++i){
+				const unsigned keep_i = sets[i], outside_i = ~keep_i & 15u;
+				if(!outside_i) continue;
+				sets[i] = outside_i;
+				seed_emit(sets, Q, orient, off, out);
+				sets[i] = keep_i;
+			}
+		}
+		sets[j] = keep;
+	}
+}
+
+// A block structure: n0 blocks with budget 0 sharing what the others leave as evenly as possible, then n1s blocks of Q - 1 slots
+// and n1 - n1s of Q slots with budget 1, then n2 blocks of Q slots with budget 2; n0 + 2*n1 + 3*n2 >= k + 1.  Blocks
+// shorter than Q are padded to a Q-window with don't-care positions.  each() lays the blocks out, calling f(pos, len, budget).
+struct SeedLayout {
+	int n0, n1, n1s, n2;
+	template<class F> void each(int first, int size, int Q, F f) const
+	{
+		const int rest = size - Q*(n1 - n1s) - (Q - 1)*n1s - Q*n2;
+		int pos = first;
+		for(int b = 0;b < n0;++b){ const int len = rest/n0 + ((b < rest % n0) ? 1 : 0); f(pos, std::min(len, Q), 0); pos += len; }
+		for(int b = 0;b < n1s;++b){ f(pos, Q - 1, 1); pos += Q - 1; }
+		for(int b = 0;b < n1 - n1s;++b){ f(pos, Q, 1); pos += Q; }
+		for(int b = 0;b < n2;++b){ f(pos, Q, 2); pos += Q; }
+	}
+};
+
 // Appends the seeds of one orientation; returns false (nothing appended) if it cannot be seeded.
-// max_exact_pos (optional): largest first slot of a budget-0 block (-1 if none); while it stays <= 32 - Q under a
+// max_exact_pos (optional): largest first slot of a padded block (-1 if none); while it stays <= 32 - Q under a
 // slot shift of the oligo the seeds of the shifted oligo are these seeds with `off` moved by the shift.
 // Q: gram length (8 bases = 16-bit codes, the first form of the scan; 9 = 18-bit codes, the second form: three times fewer
 // false seed hits per target position for the same oligo, since the code space grows faster than the code lists).
@@ -586,80 +643,39 @@ inline bool orientation_seeds(const Planes &m, uint32_t floor_, uint32_t orient,
 	for(int j = 0;j < first;++j) slot_set[j] = 0;
 	for(int j = first;j < first + size;++j) slot_set[j] = planes_nibble(m, j);
 	for(int j = first + size;j < 32;++j) slot_set[j] = 0;
-	const bool plain = ((m.a & m.c) | (m.a & m.g) | (m.a & m.t) | (m.c & m.g) | (m.c & m.t) | (m.g & m.t)) == 0;   // no IUPAC slot: code counts are known
 
-	// the structures: n1 blocks with budget 1 (Q slots each, at the 3' end of the occupied range) and
-	// n0 = k + 1 - 2*n1 blocks with budget 0 sharing the rest as evenly as possible
-	int best_n1 = -1; double best_cost = 1e30; unsigned best_codes = 0;
-	for(int n1 = 0;2*n1 <= k + 1;++n1){
-		const int n0 = k + 1 - 2*n1;
-		const int rest = size - Q*n1;
-		if(rest < 0 || (n0 > 0 && rest/n0 < MIN_SEED_BLOCK)) continue;
-		if(n0 == 0 && n1 == 0) continue;
-		unsigned codes = 0; bool ok = true;
-		int pos = first;
-		for(int b = 0;b < n0 && ok;++b){
-			const int len = rest/n0 + ((b < rest % n0) ? 1 : 0);
-			const int q = std::min<int>(len, Q);
-			const int ws = std::min(pos, 32 - Q);                         // Q-window holding the block's first q slots
-			unsigned c;
-			if(plain) c = 1u << (2*(Q - q));
-			else{
-				unsigned sets[SEED_Q_MAX];
-				for(int j = 0;j < Q;++j){ const int sl = ws + j; sets[j] = (sl >= pos && sl < pos + q) ? slot_set[sl] : 15u; }
-				c = seed_count(sets, Q);
-			}
-			if(c > MAX_SEED_CODES) ok = false;
-			codes += c;
-			pos += len;
-		}
-		for(int b = 0;b < n1 && ok;++b){
-			unsigned c;
-			if(plain) c = 1 + 3*Q;
-			else{
-				unsigned sets[SEED_Q_MAX];
-				for(int j = 0;j < Q;++j) sets[j] = slot_set[pos + j];
-				c = seed_count(sets, Q);
-				const unsigned all = c;
-				for(int j = 0;j < Q;++j){
-					const unsigned dj = (unsigned)__builtin_popcount(sets[j]);
-					if(dj < 4) c += all/dj*(4 - dj);
-				}
-			}
-			if(c > MAX_SEED_CODES) ok = false;
-			codes += c;
-			pos += Q;
-		}
-		if(!ok || codes > MAX_SEED_CODES) continue;
-		const double cost = (double)codes;
-		if(cost < best_cost){ best_cost = cost; best_n1 = n1; best_codes = codes; }
-	}
-	if(best_n1 < 0) return false;
-	(void)best_codes;
-	const int n1 = best_n1, n0 = k + 1 - 2*n1, rest = size - Q*n1;
-	int pos = first;
-	for(int b = 0;b < n0;++b){
-		const int len = rest/n0 + ((b < rest % n0) ? 1 : 0);
-		const int q = std::min<int>(len, Q);
+	auto window = [&](int pos, int len, unsigned *sets) -> int {           // the Q-window holding slots [pos, pos + len)
 		const int ws = std::min(pos, 32 - Q);
-		unsigned sets[SEED_Q_MAX];
-		for(int j = 0;j < Q;++j){ const int sl = ws + j; sets[j] = (sl >= pos && sl < pos + q) ? slot_set[sl] : 15u; }
-		seed_emit(sets, Q, orient, (uint32_t)ws, out);
-		if(max_exact_pos) *max_exact_pos = std::max(*max_exact_pos, pos);
-		pos += len;
-	}
-	for(int b = 0;b < n1;++b){
-		unsigned sets[SEED_Q_MAX];
-		for(int j = 0;j < Q;++j) sets[j] = slot_set[pos + j];
-		seed_emit(sets, Q, orient, (uint32_t)pos, out);                    // no mismatch in the window
-		for(int j = 0;j < Q;++j){                                          // exactly one, at position j
-			const unsigned keep = sets[j];
-			sets[j] = ~keep & 15u;
-			if(sets[j]) seed_emit(sets, Q, orient, (uint32_t)pos, out);
-			sets[j] = keep;
+		for(int j = 0;j < Q;++j){ const int sl = ws + j; sets[j] = (sl >= pos && sl < pos + len) ? slot_set[sl] : 15u; }
+		return ws;
+	};
+	SeedLayout best = { 0, 0, 0, 0 }; bool have = false; unsigned best_codes = 0;
+	for(int n2 = 0;3*(n2 - 1) < k + 1;++n2){
+		for(int n1 = 0;3*n2 + 2*(n1 - 1) < k + 1;++n1){
+			const int n0 = std::max(0, k + 1 - 3*n2 - 2*n1);
+			if(n0 + n1 + n2 == 0) continue;
+			for(int n1s = 0;n1s <= n1;++n1s){
+				const int rest = size - Q*(n1 - n1s) - (Q - 1)*n1s - Q*n2;
+				if(rest < 0 || (n0 > 0 && rest/n0 < MIN_SEED_BLOCK)) continue;
+				const SeedLayout lay = { n0, n1, n1s, n2 };
+				unsigned codes = 0;
+				lay.each(first, size, Q, [&](int pos, int len, int budget){
+					unsigned sets[SEED_Q_MAX];
+					window(pos, len, sets);
+					if(codes <= MAX_SEED_CODES) codes += seed_block_codes(sets, Q, budget);
+				});
+				if(codes > MAX_SEED_CODES) continue;
+				if(!have || codes < best_codes){ have = true; best = lay; best_codes = codes; }   // cost = expected seed hits per target position
+			}
 		}
-		pos += Q;
 	}
+	if(!have) return false;
+	best.each(first, size, Q, [&](int pos, int len, int budget){
+		unsigned sets[SEED_Q_MAX];
+		const int ws = window(pos, len, sets);
+		seed_emit_block(sets, Q, orient, (uint32_t)ws, budget, out);
+		if(len < Q && max_exact_pos) *max_exact_pos = std::max(*max_exact_pos, pos);
+	});
 	return true;
 }
 

@@ -13,11 +13,11 @@ from pcramp_amd import api, synth
 pytestmark = pytest.mark.gpu
 
 
-def _screener(scan=None, seed_form=None):
+def _screener(scan=None, seed_form=None, tables=None):
     """scan: PCRAMP_SCAN (2 = bit-sliced scan for everything); seed_form=1: the first form of the seed scan (k_seed)
-    instead of the second (k_seed2)."""
-    old = {k: os.environ.get(k) for k in ("PCRAMP_SCAN", "PCRAMP_SEED")}
-    for k, v in (("PCRAMP_SCAN", scan), ("PCRAMP_SEED", seed_form)):
+    instead of the second (k_seed2); tables="host": the first form's tables built on the host instead of by k_seed_tables."""
+    old = {k: os.environ.get(k) for k in ("PCRAMP_SCAN", "PCRAMP_SEED", "PCRAMP_SEED_TABLES")}
+    for k, v in (("PCRAMP_SCAN", scan), ("PCRAMP_SEED", seed_form), ("PCRAMP_SEED_TABLES", tables)):
         if v is None:
             os.environ.pop(k, None)
         else:
@@ -49,7 +49,7 @@ def _screen(d, wl, lo=0, hi=None, thr_t=1.0, mult=0.9):
 
 def test_full_c2_properties(c2):
     import torch
-    a, b, s1 = _screener(None), _screener(2), _screener(None, seed_form=1)
+    a, b, s1, s1h = _screener(None), _screener(2), _screener(None, seed_form=1), _screener(None, seed_form=1, tables="host")
     try:
         n3, fr3, rf3, cov3 = _screen(a, c2)
         n2, fr2, rf2, cov2 = _screen(b, c2)
@@ -62,6 +62,9 @@ def test_full_c2_properties(c2):
         assert n1 == n3 and np.array_equal(fr1, fr3) and np.array_equal(rf1, rf3)
         assert s1.entries() == a.entries()
         s1.close()
+        n1h, fr1h, rf1h, _ = _screen(s1h, c2)                    # ... == first form with tables built on the host
+        assert n1h == n3 and s1h.entries() == a.entries()
+        s1h.close()
         assert fr3.any() or rf3.any()
         # idempotence
         n3b, fr3b, rf3b, cov3b = _screen(a, c2)
@@ -88,6 +91,27 @@ def test_full_c2_properties(c2):
         a.close()
         b.close()
         s1.close()
+        s1h.close()
+
+
+@pytest.mark.parametrize("thr_t", [0.9, 0.85])
+def test_full_c2_low_threshold(c2, thr_t):
+    """select threshold 0.81 / 0.765 (4-5 / 5-6 mismatching slots allowed): dense seed tables (padded budget-1 blocks, budget-2
+    blocks; the densest orientations handed to the bit-sliced scan) == bit-sliced scan alone, word DB entry for entry."""
+    a, b, h = _screener(None), _screener(2), _screener(None, tables="host")
+    try:
+        hi = 2560
+        n3, fr3, rf3, cov3 = _screen(a, c2, 0, hi, thr_t)
+        n2, fr2, rf2, cov2 = _screen(b, c2, 0, hi, thr_t)
+        assert n3 == n2 and n3 > 1000
+        assert a.entries() == b.entries()
+        assert np.array_equal(fr3, fr2) and np.array_equal(rf3, rf2) and np.array_equal(cov3, cov2)
+        nh, frh, rfh, covh = _screen(h, c2, 0, hi, thr_t)          # tables built on the host == built by k_seed_tables
+        assert nh == n3 and h.entries() == a.entries()
+    finally:
+        a.close()
+        b.close()
+        h.close()
 
 
 def test_megabase_sequences_and_table_overflow():

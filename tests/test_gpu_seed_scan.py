@@ -83,7 +83,7 @@ def _border_case(rng, oracle):
     return seqs, pairs
 
 
-@pytest.mark.parametrize("thr_t,mult", [(1.0, 0.9), (0.95, 0.9), (1.0, 0.95), (0.9, 0.9)])
+@pytest.mark.parametrize("thr_t,mult", [(1.0, 0.9), (0.95, 0.9), (1.0, 0.95), (0.9, 0.9), (0.85, 0.9), (0.8, 0.9)])
 def test_tile_borders(both, oracle, thr_t, mult):
     rng = random.Random(991)
     seqs, pairs = _border_case(rng, oracle)

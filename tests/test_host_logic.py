@@ -192,6 +192,22 @@ def test_seed_filter_declines_low_thresholds():
     assert s is not None and len(s) == 1
 
 
+def test_seed_filter_structures_at_low_thresholds():
+    """floor = int(size * 0.81) (--target-threshold 0.9 x the 0.9 search multiplier): k = 4 or 5 mismatching slots; every primer
+    length has a structure with padded budget-1 blocks or a budget-2 block (code counts for plain oligos, 8-grams)."""
+    expect = {18: 277 + 25,            # 8 slots budget 2 + 8 slots budget 1 (3 + 2 >= 5)
+              19: 88 + 88 + 64,        # 5 exact + 7 + 7 with budget 1
+              20: 64 + 88 + 25,        # 5 exact + 7 + 8
+              21: 25 + 25 + 64,        # 5 exact + 8 + 8
+              22: 88 + 88 + 25,        # k = 5: 7 + 7 + 8 with budget 1
+              23: 88 + 25 + 25, 24: 75, 25: 75}
+    for size, n in expect.items():
+        word = W.centered_word(W.codes_from_text(("ACGTTGCA" * 4)[:size]))
+        s = api.host_orientation_seeds(word, int(np.float32(size) * np.float32(0.81)))
+        assert s is not None and len(s) == n, (size, None if s is None else len(s))
+        assert all(q == 8 and off + 8 <= 32 for _, q, off in s)
+
+
 def test_center_and_degeneracy_helpers_match_oracle(oracle):
     """words.center_word / word_degeneracy (used by the optimize() loop) against the oracle's Word::center / degeneracy."""
     rng = random.Random(9)
