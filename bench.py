@@ -230,15 +230,21 @@ def secondary_figures(api, synth, W, dev, stream, wl_single, scr0, pa, thr):
             args = s._targs(0.05, 9e-7, 50.0, 75.0, 40.0, 40.0)
             import ctypes as C
             s._check(s.L.pcr_thermo(s.h, ol.ctypes.data, 256, 1, C.byref(args), resb))
+            t0 = time.perf_counter()
+            s._check(s.L.pcr_thermo(s.h, ol.ctypes.data, m, 1, C.byref(args), resb))       # first call of this size: sizes the buffers
+            dt_first = time.perf_counter() - t0
             s.profile(1)
             s.profile_read_kernel(2)
+            reps = 5
             t0 = time.perf_counter()
-            s._check(s.L.pcr_thermo(s.h, ol.ctypes.data, m, 1, C.byref(args), resb))
-            dt = time.perf_counter() - t0
+            for _ in range(reps):
+                s._check(s.L.pcr_thermo(s.h, ol.ctypes.data, m, 1, C.byref(args), resb))
+            dt = (time.perf_counter() - t0) / reps
             kms, kn = s.profile_read_kernel(2)
             s.profile(0)
-            out["thermodynamics"] = {"oligos": m, "abi_oligos_per_s": m / dt, "abi_ms_per_call": dt * 1e3,
-                                     "kernel_ms": kms, "kernel_launches": int(kn)}
+            out["thermodynamics"] = {"oligos": m, "abi_oligos_per_s": m / dt, "abi_ms_per_call": dt * 1e3, "abi_ms_first_call": dt_first * 1e3,
+                                     "kernel_ms": kms / reps, "kernel_launches": int(kn) // reps,
+                                     "note": "is_valid with the homodimer test; mean of %d calls after one call of the same size (which allocates the buffers)" % reps}
         except Exception as e:                                         # noqa: BLE001
             out["thermodynamics"] = {"error": str(e)}
         # ---- C3's background path: select_words on 10 000 backgrounds at 0.8 x 0.9, then find_background_match
