@@ -294,10 +294,13 @@ def secondary_figures(api, synth, W, dev, stream, wl_single, scr0, pa, thr):
             s.select_words(trial, select_thr, 18, count=False)
             s.select_words(trial, bthr, 16, which=api.BACKGROUND, count=False)
             t0 = time.perf_counter()
+            moves.optimize_batch(s, trial, **kw)                      # first call of this size: sizes the buffers
+            dt_first = time.perf_counter() - t0
+            t0 = time.perf_counter()
             _, _, iters = moves.optimize_batch(s, trial, **kw)
             dt = time.perf_counter() - t0
             out["optimize_batch"] = {"assays": n_trial, "targets": wl["T"], "backgrounds": nbg, "ms_per_assay": dt / n_trial * 1e3,
-                                     "ms_total": dt * 1e3, "optimiser_iterations_max": max(iters), "optimiser_iterations_mean": sum(iters) / len(iters),
+                                     "ms_total": dt * 1e3, "ms_total_first_call": dt_first * 1e3, "optimiser_iterations_max": max(iters), "optimiser_iterations_mean": sum(iters) / len(iters),
                                      "note": "all trial assays in lockstep: one thermodynamics launch and one move-coverage pass per set per iteration"}
         except Exception as e:                                         # noqa: BLE001
             out.setdefault("optimize", {"error": str(e)})

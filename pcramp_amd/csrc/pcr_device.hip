@@ -245,10 +245,16 @@ __device__ __forceinline__ uint64_t make_key(uint32_t seq, int32_t loc, uint32_t
 __global__ void k_touched(const uint32_t *__restrict__ seq_count, uint32_t n, uint32_t *__restrict__ counters, uint32_t *__restrict__ touched)
 {
 	const uint32_t s = blockIdx.x*blockDim.x + threadIdx.x;
-	const bool has = s < n && seq_count[s] > 0;
+	const uint32_t fill = (s < n) ? seq_count[s] : 0u;
+	const bool has = fill > 0;
 	const uint64_t mask = __ballot(has);
 	if(!mask) return;
 	const uint32_t lane = threadIdx.x & 63u, leader = (uint32_t)__builtin_ctzll(mask);
+	{   // counters[2]: the largest bucket fill of the pass (the host shrinks oversized buckets before the next pass)
+		uint32_t mx = fill;
+		for(int d = 32;d > 0;d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d));
+		if(lane == leader) atomicMax(&counters[2], mx);
+	}
 	uint32_t base = 0;
 	if(lane == leader) base = atomicAdd(&counters[3], (uint32_t)__builtin_popcountll(mask));
 	base = __shfl(base, leader);
@@ -564,6 +570,7 @@ struct SeqSet {
 	std::vector<std::vector<pcrhost::IrrEntry> > irr_host;
 	uint64_t total_blocks = 0;
 	uint32_t n_tiles = 0, n_irr = 0;
+	uint32_t bucket_cap = 64;   // hit slots per sequence of this set's word DB (grows on overflow; per set: the target DB at 0.9 needs 64, a background DB selected at 0.72 thousands)
 	DevBuf<uint32_t> irr_perm; uint32_t irr_size_count[256];   // irregular words by size counter, largest first
 	DevBuf<uint4> planes;
 	DevBuf<uint32_t> valid, nib, tb, blk_seq, tile_seq, tile_pos0, irr_off, degen_tiles;
@@ -633,7 +640,6 @@ struct pcr_ctx {
 	DevBuf<Planes> mx_keys; uint32_t mx_n_keys = 0; DevBuf<uint32_t> mx_count;   // multiplex background: unique words of the accepted amplicons (pcr_multiplex.inc)
 	size_t amp_cap = size_t(1) << 20;
 	uint32_t n_cu = 256;        // compute units of the device (hipDeviceProp)
-	uint32_t bucket_cap = 64;   // hit slots per sequence (grows on overflow)
 	DevBuf<uint64_t> fin_scratch;   // k_finalize_big's keys
 	std::vector<uint16_t> seed_count; std::vector<uint8_t> seed_fill, seed_own;   // host scratch of the seed-table builder
 	uint32_t epoch = 0;         // pass counter tagging best[] (see HitSink)
@@ -1345,7 +1351,7 @@ int pcr_load_sequences(pcr_ctx *ctx, pcr_set which, const uint8_t *packed4, cons
 		if(hipGetLastError() != hipSuccess){ g_err = "k_transpose launch failed"; return fail(PCR_ERR_DEVICE); }
 		if((rc = run_valid(ctx, S, 0, total_blocks)) != PCR_OK) return fail(rc);
 	}
-	ctx->bucket_cap = 64;            // grown by earlier passes over other data: start small again
+	S.bucket_cap = 64;               // grown by earlier passes over other data: start small again
 	S.n_degen_tiles = 0;
 	if(n_tiles){
 		hipLaunchKernelGGL(k_tile_degen, dim3((unsigned)((n_tiles + 255)/256)), dim3(256), 0, ctx->stream, S.planes.p, S.d_blk_off.p,
@@ -1709,8 +1715,8 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 		}
 	}
 	if(ctx->seed_count.size() == 65536){ for(const pcrhost::Seed &sd : seeds){ ctx->seed_count[sd.code] = 0; ctx->seed_own[sd.code] = 0; } }
-	if(getenv("PCRAMP_DEBUG")) fprintf(stderr, "[pcramp] scan plan: %u candidates, %zu seeded orientations (%zu seeds), %zu plain, %u/%u IUPAC tiles\n",
-		ncand, or_seed.size(), n_seeds, or_plain.size(), S.n_degen_tiles, S.n_tiles);
+	if(getenv("PCRAMP_DEBUG")) fprintf(stderr, "[pcramp] scan plan: %u candidates, %zu seeded orientations (%zu seeds), %zu plain, %u/%u IUPAC tiles, %u-slot buckets\n",
+		ncand, or_seed.size(), n_seeds, or_plain.size(), S.n_degen_tiles, S.n_tiles, S.bucket_cap);
 	Scan2Tables tab_plain, tab_seedset;               // bit-sliced tables: unseedable orientations (all tiles) / seedable ones (IUPAC tiles)
 	const bool need_plain = (ctx->scan_version != 1) && !or_plain.empty();
 	const bool need_seedset = !or_seed.empty() && S.n_degen_tiles > 0;
@@ -1806,7 +1812,7 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 	uint32_t *const d_counters = S.ctrl.p, *const d_seq_count = S.ctrl.p + 8;
 	S.d_seg_hi = S.ctrl.p + 8 + S.n;
 	for(int attempt = 0;;++attempt){
-		const uint32_t cap = ctx->bucket_cap;
+		const uint32_t cap = S.bucket_cap;
 		const uint64_t n_slots = (uint64_t)S.n*cap;
 		if(n_slots >= (uint64_t(1) << 32) || n_slots*(sizeof(Hit) + sizeof(DevEntry)) > (uint64_t(96) << 30)){
 			g_err = "pcr_select_words: the per-sequence hit buckets would not fit (too many tied sites per sequence)"; return PCR_ERR_CAPACITY;
@@ -1953,13 +1959,25 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 		if((rc = mail_wait(ctx, ctx->mail_seq, h_counters)) != PCR_OK) return rc;
 		timer.next(2);
 		S.db_cap = cap; S.n_slots = n_slots;
-		if(!(h_counters[0] & 1u)) break;
+		if(!(h_counters[0] & 1u)){
+			// Buckets grown for an earlier, denser pass over this set (a DB selected with every slot shift, a lower threshold) make
+			// every consumer of this DB walk mostly empty slots (the local search: 3x slower on 2 048-slot buckets holding <= 200
+			// entries; their slot-per-thread kernels start a thread per slot): when a quarter of them would do the pass is repeated
+			// once with those.
+			if(cap > 64 && attempt < 12){
+				uint32_t want = 64;
+				while(want < h_counters[2] + h_counters[2]/16) want *= 2;
+				if(want*4 <= cap){ S.bucket_cap = want; continue; }
+			}
+			break;
+		}
 		// some sequence collected more hits than its bucket holds: grow the buckets and redo the pass
 		if(attempt >= 12 || cap >= MAX_BUCKET_CAP_GLOBAL){ g_err = "pcr_select_words: more than 65536 candidate sites in one sequence (per-sequence bucket limit)"; return PCR_ERR_CAPACITY; }
 		uint32_t want = cap*2;
 		while(want < h_counters[2] && want < MAX_BUCKET_CAP_GLOBAL) want *= 2;
-		ctx->bucket_cap = want;
+		S.bucket_cap = want;
 	}
+	if(getenv("PCRAMP_DEBUG")) fprintf(stderr, "[pcramp] pass done: %u-slot buckets, largest fill %u, %u sequences with entries\n", S.db_cap, h_counters[2], h_counters[3]);
 	S.n_touched = h_counters[3];
 	S.n_entries = S.n_touched ? 1 : 0;   // "non-empty" marker; the exact count is taken on demand (count_entries)
 	S.have_db = true;
@@ -1988,9 +2006,9 @@ int drain(pcr_ctx *ctx)
 			else{ S.n_touched = c[3]; S.n_entries = c[3] ? 1 : 0; }
 			continue;
 		}
-		uint32_t want = ctx->bucket_cap*2;
+		uint32_t want = S.bucket_cap*2;
 		while(want < c[2] && want < MAX_BUCKET_CAP_GLOBAL) want *= 2;
-		ctx->bucket_cap = std::min(want, MAX_BUCKET_CAP_GLOBAL);
+		S.bucket_cap = std::min(want, MAX_BUCKET_CAP_GLOBAL);
 		for(size_t j = i;j < pend.size();++j){
 			const pcr_ctx::Pending &q = pend[j];
 			if((rc = select_impl(ctx, (pcr_set)q.which, q.pairs.data(), (uint32_t)q.pairs.size(), q.opt5, q.opt3, q.thr, q.min_len, nullptr, false)) != PCR_OK) return rc;

@@ -11,7 +11,7 @@ s.load_sequences(wl["packed"][bsel], wl["byte_offsets"][:nbg], wl["lengths"][:nb
 thr = float(np.float32(1.0) * np.float32(0.9)); bthr = float(np.float32(0.8) * np.float32(0.9))
 kw = dict(degen=16, target_threshold=1.0, search_multiplier=0.9, amp_min=80, amp_max=200)
 mode = sys.argv[1]
-if mode == "single":
+if mode in ("single", "both"):
     s.select_words(wl["pairs"], thr, 18, True, True, count=False)
     s.select_words(wl["pairs"], bthr, 16, True, True, which=api.BACKGROUND, count=False)
     moves.optimize(s, wl["pairs"][0], **kw)
@@ -19,8 +19,10 @@ if mode == "single":
     for pp in wl["pairs"][:8]:
         moves.optimize(s, pp, **kw)
     print("single ms/assay", (time.perf_counter() - t0) / 8 * 1e3)
-else:
+if mode in ("batch", "both"):
     n = int(sys.argv[2])
+    if len(sys.argv) > 3:
+        s.load_sequences(wl["packed"][bsel], wl["byte_offsets"][:nbg], wl["lengths"][:nbg], which=api.BACKGROUND)
     trial, _, _ = s.random_assays(2024, n)
     s.select_words(trial, thr, 18, count=False)
     s.select_words(trial, bthr, 16, which=api.BACKGROUND, count=False)
