@@ -520,17 +520,23 @@ def main():
         once = T_local * ((L + 1) // 2) + P * 32 + P * T_local / 8.0
         per_pair = float(P) * T_local * ((L + 1) // 2 + 32 + 0.125)
         achieved = once / kern_s / 1e9 if kern_s > 0 else 0.0
-        seeded = select_thr >= 0.85
-        kname = "k_seed" if seeded else "k_scan2"
+        # which kernel is the scan: the second form of the seed filter at the reference's default thresholds; below that (select
+        # threshold 0.81: 4-5 mismatching slots, ~160 seed codes per orientation) the first form with tables built on the device
+        default_regime = select_thr >= 0.85
+        kname = "k_seed2" if default_regime else "k_seed"
+        klabel = ("k_seed2 (seed-filter oligo x window match scan, second form: 9-gram seeds, tables built in LDS)" if default_regime else
+                  "k_seed<true> (seed-filter oligo x window match scan, first form: dense 8-gram tables built by k_seed_tables)")
+        suffix = "" if default_regime else "_thr081"
         comparable = args.config == "C2" and args.scale == 1.0 and not args.random_primers and not args.optimize_shifts
+        is_kernel = lambda k: k == kname or k.startswith(kname + "<")    # noqa: E731
         traffic = valu = None
-        tj = load_profile_json("%s_hbm_traffic.json" % PROFILE_ROUND) if comparable else None
+        tj = load_profile_json("%s_hbm_traffic%s.json" % (PROFILE_ROUND, suffix)) if comparable else None
         if tj:
-            hit = [v for k, v in tj.items() if k.startswith(kname)]
+            hit = [v for k, v in tj.items() if is_kernel(k)]
             traffic = hit[0] if hit else None
-        vj = load_profile_json("%s_valu_pmc.json" % PROFILE_ROUND) if comparable else None
+        vj = load_profile_json("%s_valu_pmc%s.json" % (PROFILE_ROUND, suffix)) if comparable else None
         if vj:
-            hit = [v for k, v in vj.items() if k.startswith(kname)]
+            hit = [v for k, v in vj.items() if is_kernel(k)]
             if hit and hit[0].get("SQ_INSTS_VALU"):
                 insts = hit[0]["SQ_INSTS_VALU"]
                 busy_s = insts * 4.0 / (N_SIMD * VALU_CLOCK_GHZ * 1e9)
@@ -538,7 +544,7 @@ def main():
                         "frac": (busy_s / kern_s) if kern_s > 0 else None,
                         "lds_instructions_per_launch": hit[0].get("SQ_INSTS_LDS"),
                         "lds_bank_conflict_cycles_per_launch": hit[0].get("SQ_LDS_BANK_CONFLICT"),
-                        "source": "profiles/%s_valu_pmc.json (static: rocprofv3 --pmc pass of this command, committed)" % PROFILE_ROUND,
+                        "source": "profiles/%s_valu_pmc%s.json (static: rocprofv3 --pmc pass of this command, committed)" % (PROFILE_ROUND, suffix),
                         "model": "SQ_INSTS_VALU x 4 clk / (1024 SIMDs x 2.4 GHz) / kernel time"}
         hbm_frac = achieved / HBM_PEAK_GBPS
         traffic_frac = (traffic / kern_s / 1e9 / HBM_PEAK_GBPS) if (traffic and kern_s > 0) else None
@@ -559,7 +565,7 @@ def main():
                        "timed_region_s": dt,
                        "amplification_calls_set_rank0": n_set},
             "roofline": {"bound": bound,
-                         "kernel": ("k_seed (seed-filter oligo x window match scan)" if seeded else "k_scan2 (bit-sliced oligo x window match scan)"),
+                         "kernel": klabel,
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm_frac,
                          "note": "achieved = bytes one launch must read at least once (packed targets + oligos + result bits) / kernel time "
                                  "(HIP events on the launch stream, every 4th pass); the kernel is bound by VALU issue, see valu",
@@ -570,8 +576,8 @@ def main():
                                                           "reads a target once for all pairs, so this is not a fraction of any roof"},
                          "valu": valu,
                          "traffic": traffic,
-                         "traffic_source": ("profiles/%s_hbm_traffic.json (static: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                            "command, FETCH_SIZE x2 for gfx950; committed)" % PROFILE_ROUND) if traffic else None,
+                         "traffic_source": ("profiles/%s_hbm_traffic%s.json (static: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                            "command, FETCH_SIZE x2 for gfx950; committed)" % (PROFILE_ROUND, suffix)) if traffic else None,
                          "traffic_GBps": (traffic / kern_s / 1e9) if (traffic and kern_s > 0) else None,
                          "traffic_frac": traffic_frac,
                          "kernel_ms": kern_s * 1e3, "launches": int(scan_launches)},
