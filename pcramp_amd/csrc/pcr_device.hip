@@ -687,21 +687,24 @@ namespace {
 
 int drain(pcr_ctx *ctx);
 
-// HIP events around one kernel launch of a priced kernel (PCR_PROF_*), on the launch stream, while profiling is on
+// HIP events around the launches of a priced kernel (PCR_PROF_*), on the launch stream, while profiling is on.  The pair is
+// handed to the context when the scope ends (also on an error return), so no event is ever left behind.
 struct ProfScope {
 	pcr_ctx *ctx; int k; hipEvent_t e0 = nullptr, e1 = nullptr;
-	ProfScope(pcr_ctx *c, int kernel) : ctx(c), k(kernel)
+	ProfScope(pcr_ctx *c, int kernel, bool on = true) : ctx(c), k(kernel)
 	{
-		if(!ctx->prof || k <= 0 || k >= PCR_PROF_KERNELS) return;
+		if(!on || !ctx->prof || k < 0 || k >= PCR_PROF_KERNELS) return;
 		if(hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess){ if(e0) (void)hipEventDestroy(e0); e0 = e1 = nullptr; return; }
 		(void)hipEventRecord(e0, ctx->stream);
 	}
-	~ProfScope()
+	void finish()
 	{
 		if(!e0) return;
 		(void)hipEventRecord(e1, ctx->stream);
-		ctx->prof_events_k[k].push_back(std::make_pair(e0, e1));
+		((k == PCR_PROF_SCAN) ? ctx->prof_events : ctx->prof_events_k[k]).push_back(std::make_pair(e0, e1));
+		e0 = e1 = nullptr;
 	}
+	~ProfScope() { finish(); }
 };
 #define DRAIN(ctx) do{ if(!(ctx)->pending.empty()){ const int drc_ = drain(ctx); if(drc_ != PCR_OK) return drc_; } }while(0)
 
@@ -1514,6 +1517,162 @@ void plan_seed1(pcr_ctx *ctx, const std::vector<pcrhost::Candidate> &cand, std::
 	}
 }
 
+// The first form's plan when its tables are built on the HOST (passes with 5'/3' shift candidates, more than S1_MAX_OR
+// orientations, PCRAMP_SEED_TABLES=host): seeds per orientation (shift candidates inherit the unshifted oligo's), then the
+// tables of pcr_scan_seed.inc: presence bitmap + rank (the LDS image), one head word per distinct code, grouped seed lists
+// of the codes shared by several seeds.  Too many distinct codes, or a code shared by more than 255 seeds, sends the densest
+// quarter of the orientations (with shift candidates: everything) to the bit-sliced path.
+struct HostSeedPlan {
+	std::vector<pcrhost::Seed> seeds;
+	std::vector<std::vector<std::pair<uint16_t, int8_t> > > inheritors;   // per orientation: (shifted orientation, shift) sharing its seeds
+	size_t n_inherited = 0;
+	std::vector<uint32_t> image, heads, multi;
+};
+
+int plan_seed_host(pcr_ctx *ctx, const std::vector<pcrhost::Candidate> &cand, HostSeedPlan &H, std::vector<uint32_t> &or_seed, std::vector<uint32_t> &or_plain,
+	uint32_t &irr_off_mask)
+{
+	const uint32_t n_or = 2*(uint32_t)cand.size();
+	struct OrientInfo { uint32_t begin, end; int max_exact_pos; bool seeded; };
+	std::vector<OrientInfo> info;
+	std::vector<pcrhost::Seed> &seeds = H.seeds;
+	std::vector<std::vector<std::pair<uint16_t, int8_t> > > &inheritors = H.inheritors;
+	size_t &n_inherited = H.n_inherited;
+	std::vector<uint32_t> &image = H.image, &heads = H.heads, &multi = H.multi;
+	// a 5'/3' shift candidate inherits the seeds of the unshifted oligo, moved by its shift, as long as no
+	// padded 8-window would have to be clamped at the end of the word (it costs 1/10 of deriving them anew)
+	info.assign(n_or, OrientInfo());
+	inheritors.assign(n_or, std::vector<std::pair<uint16_t, int8_t> >());
+	seeds.reserve((size_t)n_or*32);
+	for(uint32_t o = 0;o < n_or;++o){
+		const pcrhost::Candidate &c = cand[o >> 1];
+		OrientInfo &me = info[o];
+		me.begin = (uint32_t)seeds.size(); me.max_exact_pos = -1;
+		const uint32_t bo = 2*c.base + (o & 1u);
+		const int32_t sh = (o & 1u) ? -c.shift : c.shift;
+		if(c.base != (o >> 1) && info[bo].seeded && info[bo].max_exact_pos <= 24 && info[bo].max_exact_pos + sh <= 24){
+			inheritors[bo].push_back(std::make_pair((uint16_t)o, (int8_t)sh));   // its seeds = those of bo with off + sh: expanded when the table is built
+			n_inherited += info[bo].end - info[bo].begin;
+			me.seeded = true; me.max_exact_pos = (info[bo].max_exact_pos < 0) ? -1 : info[bo].max_exact_pos + sh;
+		}
+		else me.seeded = pcrhost::orientation_seeds((o & 1) ? c.rc : c.fwd, c.floor_, o, seeds, &me.max_exact_pos);
+		me.end = (uint32_t)seeds.size();
+		if(me.seeded) or_seed.push_back(o); else or_plain.push_back(o);
+	}
+	if(or_seed.empty()) return PCR_OK;
+	// count[] / own[] (one entry per 8-gram code) are kept all-zero between passes: only the entries a pass touched
+	// are cleared again (two 64K-entry memsets per pass were ~8 us of the host plan)
+	if(ctx->seed_count.size() != 65536){ ctx->seed_count.assign(65536, 0); ctx->seed_own.assign(65536, 0); }
+	std::vector<uint16_t> &count = ctx->seed_count;
+	bool overflow = false;
+	uint32_t distinct = 0;
+	std::vector<uint8_t> &own = ctx->seed_own;                          // seeds listed under the code (its inheritors come on top)
+	for(;;){
+		image.assign(SEED_IMAGE_WORDS, 0u);
+		overflow = false; distinct = 0;
+		for(const pcrhost::Seed &sd : seeds){
+			uint16_t &c = count[sd.code];
+			if(c == 0){ image[sd.code >> 5] |= 1u << (sd.code & 31); ++distinct; }
+			c = (uint16_t)(c + 1 + (inheritors.empty() ? 0 : inheritors[sd.orient].size()));
+			if(c > 255){ overflow = true; break; }
+			++own[sd.code];
+		}
+		if(distinct > SEED_MAX_DISTINCT) overflow = true;
+		if(!overflow || n_inherited || or_seed.size() < 2) break;
+		// Too dense (low thresholds: hundreds of codes per orientation): hand the quarter of the seeded orientations
+		// with the longest code lists to the bit-sliced scan and count again.
+		for(const pcrhost::Seed &sd : seeds){ count[sd.code] = 0; own[sd.code] = 0; }
+		std::vector<uint32_t> by_len(or_seed);
+		std::stable_sort(by_len.begin(), by_len.end(), [&](uint32_t x, uint32_t y){ return info[x].end - info[x].begin > info[y].end - info[y].begin; });
+		const size_t n_drop = (by_len.size() + 3)/4;
+		std::vector<uint8_t> drop(n_or, 0);
+		for(size_t i = 0;i < n_drop;++i) drop[by_len[i]] = 1;
+		std::vector<pcrhost::Seed> kept; kept.reserve(seeds.size());
+		for(uint32_t o = 0;o < n_or;++o){
+			const uint32_t b = info[o].begin, e = info[o].end;
+			info[o].begin = (uint32_t)kept.size();
+			if(!drop[o]) kept.insert(kept.end(), seeds.begin() + b, seeds.begin() + e);
+			info[o].end = (uint32_t)kept.size();
+			if(drop[o]) info[o].seeded = false;
+		}
+		seeds.swap(kept);
+		or_seed.clear(); or_plain.clear();
+		for(uint32_t o = 0;o < n_or;++o){ if(info[o].seeded) or_seed.push_back(o); else or_plain.push_back(o); }
+	}
+	for(const pcrhost::Seed &sd : seeds){                                 // slot offsets at which forward seeds sit (irregular-word scan)
+		if(sd.orient & 1u) continue;
+		irr_off_mask |= 1u << sd.off;
+		if(!inheritors.empty()){ for(const std::pair<uint16_t, int8_t> &in : inheritors[sd.orient]) irr_off_mask |= 1u << (sd.off + in.second); }
+	}
+	if(overflow){
+		or_plain.clear(); or_seed.clear(); image.clear();
+		for(uint32_t o = 0;o < n_or;++o) or_plain.push_back(o);
+	}
+	else{
+		uint16_t *rank16 = (uint16_t *)(image.data() + SEED_BITMAP_WORDS);
+		uint32_t run = 0;
+		for(uint32_t w = 0;w < SEED_BITMAP_WORDS;++w){ rank16[w] = (uint16_t)run; run += (uint32_t)__builtin_popcount(image[w]); }
+		heads.assign(distinct, 0u);
+		// first pass: reserve the multi ranges (head = start << 8 | filled so far); second: fill
+		uint32_t n_multi = 0;
+		for(const pcrhost::Seed &sd : seeds){
+			const uint32_t h = rank16[sd.code >> 5] + (uint32_t)__builtin_popcount(image[sd.code >> 5] & ((1u << (sd.code & 31)) - 1u));
+			if(count[sd.code] == 1){ heads[h] = SEED_SINGLE | ((uint32_t)sd.orient << 8) | sd.off; continue; }
+			if(heads[h] == 0){ heads[h] = 0x40000000u | n_multi; n_multi += own[sd.code]; }   // bit 30: range reserved, low bits = start
+		}
+		std::vector<uint32_t> raw(n_multi, 0u);                  // per code, in generation order: orient | off << 24
+		std::vector<uint8_t> &fill = ctx->seed_fill; fill.assign(distinct, 0);
+		for(const pcrhost::Seed &sd : seeds){
+			if(count[sd.code] == 1) continue;
+			const uint32_t h = rank16[sd.code >> 5] + (uint32_t)__builtin_popcount(image[sd.code >> 5] & ((1u << (sd.code & 31)) - 1u));
+			const uint32_t start = heads[h] & 0x3FFFFFFFu;
+			raw[start + fill[h]++] = (uint32_t)sd.orient | ((uint32_t)sd.off << 24);
+		}
+		// Group the seeds of a code: slot shifts of one oligo orientation (consecutive candidates, so consecutive
+		// here) whose base-aligned offset boff = off - shift is the same lie over the same target bases; their
+		// match count is taken once, with the unshifted orientation at window x - boff (layout: pcr_scan_seed.inc).
+		multi.clear(); multi.reserve(n_multi + n_multi/2 + 16);
+		for(uint32_t h = 0;h < distinct;++h){
+			if(heads[h] & SEED_SINGLE) continue;
+			const uint32_t start = heads[h] & 0x3FFFFFFFu, n = fill[h];
+			const uint32_t out0 = (uint32_t)multi.size();
+			uint32_t header_at = 0, members = 0, cur_base = 0xFFFFFFFFu; int32_t cur_boff = -1;
+			for(uint32_t e = 0;e < n;++e){
+				const uint32_t sd = raw[start + e], orient = sd & 0xFFFFu, off = sd >> 24;
+				const pcrhost::Candidate &c = cand[orient >> 1];
+				const int32_t sh = (orient & 1u) ? -c.shift : c.shift;
+				int32_t boff = (int32_t)off - sh;
+				uint32_t base_orient = 2*c.base + (orient & 1u);
+				if(boff < 0 || boff > 24){ boff = (int32_t)off; base_orient = orient; }   // the unshifted window would leave the word: stands alone
+				if(members && base_orient == cur_base && boff == cur_boff && members < 256){
+					multi.push_back(sd); ++members;
+					multi[header_at] = SEED_GROUP | cur_base | ((uint32_t)cur_boff << 16) | ((members - 1) << 21);
+				}
+				else{
+					header_at = (uint32_t)multi.size(); members = 1; cur_base = base_orient; cur_boff = boff;
+					multi.push_back(SEED_GROUP | cur_base | ((uint32_t)cur_boff << 16));
+					multi.push_back(sd);
+				}
+				// the shift candidates that inherit this seed: same target bases, off moved by their shift
+				if(!inheritors.empty()){
+					for(const std::pair<uint16_t, int8_t> &in : inheritors[orient]){
+						if(members == 256){        // header field full: open another group with the same leader
+							header_at = (uint32_t)multi.size(); members = 0;
+							multi.push_back(SEED_GROUP | cur_base | ((uint32_t)cur_boff << 16));
+						}
+						multi.push_back((uint32_t)in.first | ((uint32_t)((int32_t)off + in.second) << 24)); ++members;
+						multi[header_at] = SEED_GROUP | cur_base | ((uint32_t)cur_boff << 16) | ((members - 1) << 21);
+					}
+				}
+			}
+			heads[h] = (out0 << 9) | ((uint32_t)multi.size() - out0);
+		}
+		n_multi = (uint32_t)multi.size();
+		if(n_multi >= (1u << 22)){ ctx->seed_count.clear(); g_err = "pcr_select_words: seed table too large"; return PCR_ERR_CAPACITY; }
+	}
+	return PCR_OK;
+}
+
 // pcr_select_words proper.  async: enqueue one attempt and return without looking at the counters
 // (pcr_screen_device; the caller records the pass as pending).
 int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_pairs, int optimize_5, int optimize_3,
@@ -1549,15 +1708,11 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 	// version 2: bit-sliced counter for everything.  version 1: one popcount per (window, orientation).
 	const uint32_t n_or = 2*ncand;
 	std::vector<uint32_t> or_seed, or_plain;          // orientation ids
-	std::vector<pcrhost::Seed> seeds;
-	std::vector<std::vector<std::pair<uint16_t, int8_t> > > inheritors;   // per orientation: (shifted orientation, shift) sharing its seeds
-	size_t n_inherited = 0;
+	HostSeedPlan H;                                   // first form with host-built tables only
 	uint32_t irr_off_mask = 0;
 	// The second form of the seed scan (pcr_scan_seed2.inc) takes the pass when no 5'/3' shift candidates are asked for and
 	// the orientations and their 9-gram seeds fit its LDS budget; the host then only LISTS the seeds (from a cache keyed by
 	// oligo and floor: between two optimiser iterations most oligos stay what they were).
-	struct OrientInfo { uint32_t begin, end; int max_exact_pos; bool seeded; };
-	std::vector<OrientInfo> info;
 	bool use_seed2 = false;
 	if(ctx->scan_version == 3 && !ctx->force_seed1 && !optimize_5 && !optimize_3 && n_or <= S2_MAX_OR){
 		use_seed2 = plan_seed2(ctx, cand, or_seed, or_plain, irr_off_mask);
@@ -1573,148 +1728,15 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 	}
 	if(use_seed2 || dev_tables){ /* planned */ }
 	else if(ctx->scan_version == 3 && n_or <= 65535){
-		// a 5'/3' shift candidate inherits the seeds of the unshifted oligo, moved by its shift, as long as no
-		// padded 8-window would have to be clamped at the end of the word (it costs 1/10 of deriving them anew)
-		info.assign(n_or, OrientInfo());
-		inheritors.assign(n_or, std::vector<std::pair<uint16_t, int8_t> >());
-		seeds.reserve((size_t)n_or*32);
-		for(uint32_t o = 0;o < n_or;++o){
-			const pcrhost::Candidate &c = cand[o >> 1];
-			OrientInfo &me = info[o];
-			me.begin = (uint32_t)seeds.size(); me.max_exact_pos = -1;
-			const uint32_t bo = 2*c.base + (o & 1u);
-			const int32_t sh = (o & 1u) ? -c.shift : c.shift;
-			if(c.base != (o >> 1) && info[bo].seeded && info[bo].max_exact_pos <= 24 && info[bo].max_exact_pos + sh <= 24){
-				inheritors[bo].push_back(std::make_pair((uint16_t)o, (int8_t)sh));   // its seeds = those of bo with off + sh: expanded when the table is built
-				n_inherited += info[bo].end - info[bo].begin;
-				me.seeded = true; me.max_exact_pos = (info[bo].max_exact_pos < 0) ? -1 : info[bo].max_exact_pos + sh;
-			}
-			else me.seeded = pcrhost::orientation_seeds((o & 1) ? c.rc : c.fwd, c.floor_, o, seeds, &me.max_exact_pos);
-			me.end = (uint32_t)seeds.size();
-			if(me.seeded) or_seed.push_back(o); else or_plain.push_back(o);
-		}
+		const int prc = plan_seed_host(ctx, cand, H, or_seed, or_plain, irr_off_mask);
+		// (the counters the table build touched are cleared again whatever happened: they stay all-zero between passes)
+		if(ctx->seed_count.size() == 65536){ for(const pcrhost::Seed &sd : H.seeds){ ctx->seed_count[sd.code] = 0; ctx->seed_own[sd.code] = 0; } }
+		if(prc != PCR_OK) return prc;
 	}
 	else{ for(uint32_t o = 0;o < n_or;++o) or_plain.push_back(o); }
-	// Tables of the seed scan (layout: pcr_scan_seed.inc): presence bitmap + rank (the LDS image), one head
-	// word per distinct code, seed lists of the codes shared by several seeds.  Too many distinct codes, or a
-	// code shared by more than 255 seeds, sends everything to the bit-sliced path.
-	std::vector<uint32_t> image, heads, multi;
 	SeedTables ST; memset(&ST, 0, sizeof(ST));
 	Seed2Tables ST2; memset(&ST2, 0, sizeof(ST2));
-	const size_t n_seeds = use_seed2 ? ctx->s2_seeds.size() : dev_tables ? ctx->s1_seeds.size() : seeds.size() + n_inherited;
-	if(!or_seed.empty() && !use_seed2 && !dev_tables){
-		// count[] / own[] (one entry per 8-gram code) are kept all-zero between passes: only the entries a pass touched
-		// are cleared again (two 64K-entry memsets per pass were ~8 us of the host plan)
-		if(ctx->seed_count.size() != 65536){ ctx->seed_count.assign(65536, 0); ctx->seed_own.assign(65536, 0); }
-		std::vector<uint16_t> &count = ctx->seed_count;
-		bool overflow = false;
-		uint32_t distinct = 0;
-		std::vector<uint8_t> &own = ctx->seed_own;                          // seeds listed under the code (its inheritors come on top)
-		for(;;){
-			image.assign(SEED_IMAGE_WORDS, 0u);
-			overflow = false; distinct = 0;
-			for(const pcrhost::Seed &sd : seeds){
-				uint16_t &c = count[sd.code];
-				if(c == 0){ image[sd.code >> 5] |= 1u << (sd.code & 31); ++distinct; }
-				c = (uint16_t)(c + 1 + (inheritors.empty() ? 0 : inheritors[sd.orient].size()));
-				if(c > 255){ overflow = true; break; }
-				++own[sd.code];
-			}
-			if(distinct > SEED_MAX_DISTINCT) overflow = true;
-			if(!overflow || n_inherited || or_seed.size() < 2) break;
-			// Too dense (low thresholds: hundreds of codes per orientation): hand the quarter of the seeded orientations
-			// with the longest code lists to the bit-sliced scan and count again.
-			for(const pcrhost::Seed &sd : seeds){ count[sd.code] = 0; own[sd.code] = 0; }
-			std::vector<uint32_t> by_len(or_seed);
-			std::stable_sort(by_len.begin(), by_len.end(), [&](uint32_t x, uint32_t y){ return info[x].end - info[x].begin > info[y].end - info[y].begin; });
-			const size_t n_drop = (by_len.size() + 3)/4;
-			std::vector<uint8_t> drop(n_or, 0);
-			for(size_t i = 0;i < n_drop;++i) drop[by_len[i]] = 1;
-			std::vector<pcrhost::Seed> kept; kept.reserve(seeds.size());
-			for(uint32_t o = 0;o < n_or;++o){
-				const uint32_t b = info[o].begin, e = info[o].end;
-				info[o].begin = (uint32_t)kept.size();
-				if(!drop[o]) kept.insert(kept.end(), seeds.begin() + b, seeds.begin() + e);
-				info[o].end = (uint32_t)kept.size();
-				if(drop[o]) info[o].seeded = false;
-			}
-			seeds.swap(kept);
-			or_seed.clear(); or_plain.clear();
-			for(uint32_t o = 0;o < n_or;++o){ if(info[o].seeded) or_seed.push_back(o); else or_plain.push_back(o); }
-		}
-		for(const pcrhost::Seed &sd : seeds){                                 // slot offsets at which forward seeds sit (irregular-word scan)
-			if(sd.orient & 1u) continue;
-			irr_off_mask |= 1u << sd.off;
-			if(!inheritors.empty()){ for(const std::pair<uint16_t, int8_t> &in : inheritors[sd.orient]) irr_off_mask |= 1u << (sd.off + in.second); }
-		}
-		if(overflow){
-			or_plain.clear(); or_seed.clear(); image.clear();
-			for(uint32_t o = 0;o < n_or;++o) or_plain.push_back(o);
-		}
-		else{
-			uint16_t *rank16 = (uint16_t *)(image.data() + SEED_BITMAP_WORDS);
-			uint32_t run = 0;
-			for(uint32_t w = 0;w < SEED_BITMAP_WORDS;++w){ rank16[w] = (uint16_t)run; run += (uint32_t)__builtin_popcount(image[w]); }
-			heads.assign(distinct, 0u);
-			// first pass: reserve the multi ranges (head = start << 8 | filled so far); second: fill
-			uint32_t n_multi = 0;
-			for(const pcrhost::Seed &sd : seeds){
-				const uint32_t h = rank16[sd.code >> 5] + (uint32_t)__builtin_popcount(image[sd.code >> 5] & ((1u << (sd.code & 31)) - 1u));
-				if(count[sd.code] == 1){ heads[h] = SEED_SINGLE | ((uint32_t)sd.orient << 8) | sd.off; continue; }
-				if(heads[h] == 0){ heads[h] = 0x40000000u | n_multi; n_multi += own[sd.code]; }   // bit 30: range reserved, low bits = start
-			}
-			std::vector<uint32_t> raw(n_multi, 0u);                  // per code, in generation order: orient | off << 24
-			std::vector<uint8_t> &fill = ctx->seed_fill; fill.assign(distinct, 0);
-			for(const pcrhost::Seed &sd : seeds){
-				if(count[sd.code] == 1) continue;
-				const uint32_t h = rank16[sd.code >> 5] + (uint32_t)__builtin_popcount(image[sd.code >> 5] & ((1u << (sd.code & 31)) - 1u));
-				const uint32_t start = heads[h] & 0x3FFFFFFFu;
-				raw[start + fill[h]++] = (uint32_t)sd.orient | ((uint32_t)sd.off << 24);
-			}
-			// Group the seeds of a code: slot shifts of one oligo orientation (consecutive candidates, so consecutive
-			// here) whose base-aligned offset boff = off - shift is the same lie over the same target bases; their
-			// match count is taken once, with the unshifted orientation at window x - boff (layout: pcr_scan_seed.inc).
-			multi.clear(); multi.reserve(n_multi + n_multi/2 + 16);
-			for(uint32_t h = 0;h < distinct;++h){
-				if(heads[h] & SEED_SINGLE) continue;
-				const uint32_t start = heads[h] & 0x3FFFFFFFu, n = fill[h];
-				const uint32_t out0 = (uint32_t)multi.size();
-				uint32_t header_at = 0, members = 0, cur_base = 0xFFFFFFFFu; int32_t cur_boff = -1;
-				for(uint32_t e = 0;e < n;++e){
-					const uint32_t sd = raw[start + e], orient = sd & 0xFFFFu, off = sd >> 24;
-					const pcrhost::Candidate &c = cand[orient >> 1];
-					const int32_t sh = (orient & 1u) ? -c.shift : c.shift;
-					int32_t boff = (int32_t)off - sh;
-					uint32_t base_orient = 2*c.base + (orient & 1u);
-					if(boff < 0 || boff > 24){ boff = (int32_t)off; base_orient = orient; }   // the unshifted window would leave the word: stands alone
-					if(members && base_orient == cur_base && boff == cur_boff && members < 256){
-						multi.push_back(sd); ++members;
-						multi[header_at] = SEED_GROUP | cur_base | ((uint32_t)cur_boff << 16) | ((members - 1) << 21);
-					}
-					else{
-						header_at = (uint32_t)multi.size(); members = 1; cur_base = base_orient; cur_boff = boff;
-						multi.push_back(SEED_GROUP | cur_base | ((uint32_t)cur_boff << 16));
-						multi.push_back(sd);
-					}
-					// the shift candidates that inherit this seed: same target bases, off moved by their shift
-					if(!inheritors.empty()){
-						for(const std::pair<uint16_t, int8_t> &in : inheritors[orient]){
-							if(members == 256){        // header field full: open another group with the same leader
-								header_at = (uint32_t)multi.size(); members = 0;
-								multi.push_back(SEED_GROUP | cur_base | ((uint32_t)cur_boff << 16));
-							}
-							multi.push_back((uint32_t)in.first | ((uint32_t)((int32_t)off + in.second) << 24)); ++members;
-							multi[header_at] = SEED_GROUP | cur_base | ((uint32_t)cur_boff << 16) | ((members - 1) << 21);
-						}
-					}
-				}
-				heads[h] = (out0 << 9) | ((uint32_t)multi.size() - out0);
-			}
-			n_multi = (uint32_t)multi.size();
-			if(n_multi >= (1u << 22)){ ctx->seed_count.clear(); g_err = "pcr_select_words: seed table too large"; return PCR_ERR_CAPACITY; }
-		}
-	}
-	if(ctx->seed_count.size() == 65536){ for(const pcrhost::Seed &sd : seeds){ ctx->seed_count[sd.code] = 0; ctx->seed_own[sd.code] = 0; } }
+	const size_t n_seeds = use_seed2 ? ctx->s2_seeds.size() : dev_tables ? ctx->s1_seeds.size() : H.seeds.size() + H.n_inherited;
 	if(getenv("PCRAMP_DEBUG")) fprintf(stderr, "[pcramp] scan plan: %u candidates, %zu seeded orientations (%zu seeds), %zu plain, %u/%u IUPAC tiles, %u-slot buckets\n",
 		ncand, or_seed.size(), n_seeds, or_plain.size(), S.n_degen_tiles, S.n_tiles, S.bucket_cap);
 	Scan2Tables tab_plain, tab_seedset;               // bit-sliced tables: unseedable orientations (all tiles) / seedable ones (IUPAC tiles)
@@ -1728,7 +1750,7 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 		size_t bytes = ncand*(2*sizeof(uint4) + sizeof(uint32_t)) + 1024;
 		bytes += (tab_plain.tab.size() + tab_plain.bias.size() + or_plain.size() + 256)*sizeof(uint32_t);
 		bytes += (tab_seedset.tab.size() + tab_seedset.bias.size() + or_seed.size() + 256)*sizeof(uint32_t);
-		bytes += (image.size() + heads.size() + multi.size() + 64)*sizeof(uint32_t);
+		bytes += (H.image.size() + H.heads.size() + H.multi.size() + 64)*sizeof(uint32_t);
 		std::vector<uint4> &masks2 = ctx->s2_masks; std::vector<uint8_t> &floors2 = ctx->s2_floors;
 		if(use_seed2){
 			// per orientation: the four base-set planes spread to even bits (slot k -> bit 2k), slots 0..15 | 16..31
@@ -1772,10 +1794,10 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 			const std::vector<uint32_t> m = pad256(or_seed);
 			d_map_seedset = st.put(m.data(), m.size());
 		}
-		if(!image.empty()){
-			ST.image = st.put(image.data(), image.size());
-			ST.heads = st.put(heads.data(), heads.size());
-			ST.multi = multi.empty() ? ST.heads : st.put(multi.data(), multi.size());
+		if(!H.image.empty()){
+			ST.image = st.put(H.image.data(), H.image.size());
+			ST.heads = st.put(H.heads.data(), H.heads.size());
+			ST.multi = H.multi.empty() ? ST.heads : st.put(H.multi.data(), H.multi.size());
 		}
 		const uint32_t *d_s1_seeds = nullptr;
 		if(build_tables){
@@ -1833,12 +1855,8 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 		for(uint32_t k = std::min<uint32_t>(min_oligo_length, 256);k < 256;++k) n_live += S.irr_size_count[k];
 		bool irr_fused = false;                           // scanned by extra workgroups of k_seed
 		if(S.n_tiles){
-			hipEvent_t e0 = nullptr, e1 = nullptr;
-			const bool timed = ctx->prof && (ctx->prof_pass++ % ctx->prof_stride) == 0;   // an event between two kernels costs a ~6 us queue bubble
-			if(timed){
-				HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
-				HIP_TRY(hipEventRecord(e0, ctx->stream));
-			}
+			// events around the scan launches of every prof_stride-th pass (an event between two kernels costs a ~6 us queue bubble)
+			ProfScope scan_prof(ctx, PCR_PROF_SCAN, ctx->prof && (ctx->prof_pass++ % ctx->prof_stride) == 0);
 			if(ctx->scan_version == 1){
 				hipLaunchKernelGGL(k_scan, dim3(S.n_tiles), dim3(SCAN_THREADS), 0, ctx->stream, S.planes.p, S.valid.p,
 					S.d_blk_off.p, S.d_len.p, S.d_active.p, S.tile_seq.p, S.tile_pos0.p, ctx->d_cand_fwd, ctx->d_cand_rc,
@@ -1901,10 +1919,7 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 						S.n_degen_tiles, d_map_seedset)) != PCR_OK) return rc;
 				}
 			}
-			if(timed){
-				HIP_TRY(hipEventRecord(e1, ctx->stream));
-				ctx->prof_events.push_back(std::make_pair(e0, e1));
-			}
+			scan_prof.finish();
 		}
 		if(n_live && !irr_fused){
 			const unsigned irr_grid = (n_live + IRR_THREADS*IRR_PER_LANE - 1)/(IRR_THREADS*IRR_PER_LANE);
