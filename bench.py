@@ -374,13 +374,28 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("gloo" if rehearsal else "nccl", rank=rank, world_size=world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     if rehearsal:
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev_t = torch.device("cuda", local_rank)
+    if use_dist:
+        # RCCL (version banner) and gloo (peer list) write to file descriptor 1 when the communicator comes up: send that to
+        # stderr so that the JSON line is the only thing on stdout
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo" if rehearsal else "nccl", rank=rank, world_size=world)
+            warm = torch.zeros(1, device="cpu" if rehearsal else dev_t)
+            dist.all_reduce(warm)                      # the communicator is created by the first collective
+            if not rehearsal:
+                torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
 
     thr_t, mult = args.target_threshold, args.search_multiplier
     select_thr = float(np.float32(thr_t) * np.float32(mult))
