@@ -37,7 +37,10 @@ typedef struct { uint64_t w[2]; } pcr_word128;
 /* One trial assay: PCR::f / PCR::r (assay.h:117-118). */
 typedef struct { pcr_word128 f, r; } pcr_pair;
 
-typedef enum { PCR_SET_TARGET = 0, PCR_SET_BACKGROUND = 1 } pcr_set;
+/* The sequence sets of a context: target_seq, background_seq (main.cpp:257-344) and multiplex_background_seq, the amplicons of
+ * the assays accepted so far as sequences (main.cpp:989-1001; templates of find_multiplex_background_match). */
+typedef enum { PCR_SET_TARGET = 0, PCR_SET_BACKGROUND = 1, PCR_SET_MULTIPLEX = 2 } pcr_set;
+#define PCR_N_SETS 4   /* + one internal scratch set */
 
 /* The `Options` fields (pcramp.h:83-128) that Sequence::pack reads (sequence.cpp:92-96). */
 typedef struct {
@@ -294,6 +297,31 @@ typedef struct {
  * passes them to pcr_multiplex_load and splits the targets at begin, (begin+end)/2 and end (main.cpp:1008-1017). */
 int64_t pcr_collect_amplicons(pcr_ctx *ctx, pcr_set which, const pcr_pair *pair, float threshold, int32_t amp_min, int32_t amp_max,
 	pcr_amplicon *out, uint64_t cap);
+
+/* ---- The multiplex compatibility filter of the trial loop (main.cpp:744-803), batched over the trial assays */
+
+typedef struct {
+	pcr_thermo_args thermo;        /* salt, primer_strand, max_dimer: PCR::multiplex_compatible (pcr_assay.cpp:815-852) */
+	float background_threshold;    /* opt.background_threshold (find_multiplex_background_match) */
+	int32_t use_taq_mama;
+	float target_threshold;        /* opt.target_threshold, amplicon range: collect_unique_amplicons (main.cpp:787-789) */
+	int32_t amp_min, amp_max;
+} pcr_multiplex_screen_args;
+
+/* For every trial assay t, what main.cpp:744-803 computes against the pool of accepted assays:
+ *   compatible[t]      = every pool assay is multiplex_compatible with it (:748-752);
+ *   multiplex_cover[t] = weighted_coverage of trial[t].find_multiplex_background_match over PCR_SET_MULTIPLEX (:767-771);
+ *   pool_cover[t]      = weighted_coverage of the union, over the pool assays, of find_multiplex_background_match against the
+ *                        trial's own unique amplicons (collect_unique_amplicons on the targets at target_threshold; amplicon
+ *                        Sequences carry the default weight 1, so this is the number of unique amplicons some pool assay
+ *                        matches; :786-803).
+ * The two covers are computed for the trials with detail[t] != 0 (NULL: all) that are compatible; others get 0.  The reference
+ * gates them on best_score < s and on max_background_cover as it walks the trials (:754, :778): the caller applies those to
+ * the returned numbers.  One thermodynamics launch for all (trial, pool) pairs, one alignment pass for all trials over the
+ * multiplex set, one for all pool assays over all trials' amplicons (loaded into an internal scratch set).  Needs the target
+ * word DB selected for the trial batch (as pcr_collect_amplicons does). */
+int pcr_multiplex_screen(pcr_ctx *ctx, const pcr_pair *trial, uint32_t n_trial, const pcr_pair *pool, uint32_t n_pool,
+	const pcr_multiplex_screen_args *args, const uint8_t *detail, uint8_t *compatible, float *multiplex_cover, float *pool_cover);
 
 /* ---- Random assay sampler (scope row f-2) */
 

@@ -24,7 +24,7 @@ import numpy as np
 
 from . import words as W
 
-TARGET, BACKGROUND = 0, 1
+TARGET, BACKGROUND, MULTIPLEX = 0, 1, 2       # pcr_set: target_seq, background_seq, multiplex_background_seq (accepted amplicons)
 
 
 class PcrError(RuntimeError):
@@ -70,6 +70,11 @@ class SampleInfo(C.Structure):
                 ("sequence_iterations", C.c_uint32), ("assay_iterations", C.c_uint32)]
 
 
+class MultiplexScreenArgs(C.Structure):
+    _fields_ = [("thermo", ThermoArgs), ("background_threshold", C.c_float), ("use_taq_mama", C.c_int32),
+                ("target_threshold", C.c_float), ("amp_min", C.c_int32), ("amp_max", C.c_int32)]
+
+
 class ThermoResult(C.Structure):
     _fields_ = [("valid", C.c_uint32), ("n_expansions", C.c_uint32), ("tm", C.c_float), ("dH", C.c_float), ("dS", C.c_float),
                 ("hairpin_tm", C.c_float), ("homodimer_tm", C.c_float), ("dG", C.c_float)]
@@ -107,7 +112,7 @@ ABI_SYMBOLS = [
     "pcr_synchronize", "pcr_host_irregular_words", "pcr_host_window_valid", "pcr_host_candidates",
     "pcr_host_orientation_seeds", "pcr_host_move_trials",
     "pcr_sw_align_words", "pcr_background_match", "pcr_multiplex_match",
-    "pcr_thermo", "pcr_dimer", "pcr_multiplex_compatible",
+    "pcr_thermo", "pcr_dimer", "pcr_multiplex_compatible", "pcr_multiplex_screen",
     "pcr_random_assays", "pcr_host_rand_r", "pcr_host_max_overlap", "pcr_host_oligo_overlap", "pcr_host_pool_overlaps",
     "pcr_multiplex_load", "pcr_multiplex_coverage", "pcr_collect_amplicons",
     "pcr_format_oligos", "pcr_format_header", "pcr_format_iteration", "pcr_format_assay", "pcr_format_footer",
@@ -665,6 +670,29 @@ class Screener:
         args = self._targs(salt, primer_strand, 0.0, 0.0, 0.0, max_dimer)
         self._check(self.L.pcr_multiplex_compatible(self.h, a.ctypes.data, b.ctypes.data, a.shape[0], C.byref(args), out.ctypes.data))
         return out[:a.shape[0]].astype(bool)
+
+    def multiplex_screen(self, trial, pool, salt=0.05, primer_strand=9e-7, max_dimer=40.0, background_threshold=0.8, use_taq_mama=False,
+                         target_threshold=1.0, amp_min=80, amp_max=200, detail=None):
+        """The multiplex compatibility filter of the trial loop (main.cpp:744-803) for all trial assays ->
+        (compatible bool[n], multiplex_cover float32[n], pool_cover float32[n]).  The accepted amplicons must be loaded as the
+        MULTIPLEX set (sequences) and the target word DB selected for the trial batch."""
+        t = W.pairs_array(list(trial))
+        n = t.shape[0]
+        pp = W.pairs_array(list(pool)) if pool else np.zeros((1, 4), np.uint64)
+        a = MultiplexScreenArgs()
+        a.thermo = self._targs(salt, primer_strand, 0.0, 0.0, 0.0, max_dimer)
+        a.background_threshold, a.use_taq_mama = background_threshold, int(bool(use_taq_mama))
+        a.target_threshold, a.amp_min, a.amp_max = target_threshold, int(amp_min), int(amp_max)
+        ok = np.zeros(max(n, 1), np.uint8)
+        mc = np.zeros(max(n, 1), np.float32)
+        pc = np.zeros(max(n, 1), np.float32)
+        d = None if detail is None else np.ascontiguousarray(detail, dtype=np.uint8)
+        fn = self.L.pcr_multiplex_screen
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(MultiplexScreenArgs), C.c_void_p, C.c_void_p,
+                       C.c_void_p, C.c_void_p]
+        self._check(fn(self.h, t.ctypes.data, n, pp.ctypes.data if pool else None, len(pool) if pool else 0, C.byref(a),
+                       d.ctypes.data if d is not None else None, ok.ctypes.data, mc.ctypes.data, pc.ctypes.data))
+        return ok[:n].astype(bool), mc[:n], pc[:n]
 
     def profile(self, on=True):
         self._check(self.L.pcr_profile_enable(self.h, int(on)))

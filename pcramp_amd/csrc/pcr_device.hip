@@ -609,7 +609,7 @@ struct pcr_ctx {
 	bool own_stream = false;
 	pcr_params params;
 	pcrhost::PackFilter filt;
-	SeqSet sets[2];
+	SeqSet sets[PCR_N_SETS];   // target, background, multiplex (accepted amplicons), scratch (pcr_multiplex_screen's trial amplicons)
 	// scratch
 	DevBuf<uint32_t> best, counters, mask, status;
 	int scan_version = 3;
@@ -706,6 +706,10 @@ struct ProfScope {
 	}
 	~ProfScope() { finish(); }
 };
+// the sets a caller may name (the fourth slot is internal)
+constexpr int PCR_SET_SCRATCH = 3;
+inline bool set_ok(pcr_set which) { return (unsigned)which <= (unsigned)PCR_SET_MULTIPLEX; }
+#define CHECK_SET(which) do{ if(!set_ok(which)){ g_err = "unknown sequence set (PCR_SET_TARGET, PCR_SET_BACKGROUND or PCR_SET_MULTIPLEX)"; return PCR_ERR_ARG; } }while(0)
 #define DRAIN(ctx) do{ if(!(ctx)->pending.empty()){ const int drc_ = drain(ctx); if(drc_ != PCR_OK) return drc_; } }while(0)
 
 struct HostTimer {
@@ -1214,7 +1218,7 @@ void pcr_destroy(pcr_ctx *ctx)
 	}
 	for(auto &pr : ctx->prof_events){ (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
 	for(int k = 0;k < PCR_PROF_KERNELS;++k){ for(auto &pr : ctx->prof_events_k[k]){ (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); } }
-	for(int s = 0;s < 2;++s) ctx->sets[s].release();
+	for(int s = 0;s < PCR_N_SETS;++s) ctx->sets[s].release();
 	ctx->best.release();
 	ctx->counters.release(); ctx->mask.release(); ctx->status.release(); ctx->hits.release();
 	ctx->s1_image.release(); ctx->s1_heads.release(); ctx->s1_multi.release();
@@ -1231,8 +1235,8 @@ void pcr_destroy(pcr_ctx *ctx)
 	delete ctx;
 }
 
-uint32_t pcr_num_sequences(pcr_ctx *ctx, pcr_set which) { return ctx ? ctx->sets[which].n : 0; }
-uint64_t pcr_bitset_words(pcr_ctx *ctx, pcr_set which) { return ctx ? (ctx->sets[which].n + 63)/64 : 0; }
+uint32_t pcr_num_sequences(pcr_ctx *ctx, pcr_set which) { return (ctx && set_ok(which)) ? ctx->sets[which].n : 0; }
+uint64_t pcr_bitset_words(pcr_ctx *ctx, pcr_set which) { return (ctx && set_ok(which)) ? (ctx->sets[which].n + 63)/64 : 0; }
 
 int pcr_synchronize(pcr_ctx *ctx)
 {
@@ -1243,10 +1247,21 @@ int pcr_synchronize(pcr_ctx *ctx)
 	return PCR_OK;
 }
 
+static int load_sequences_impl(pcr_ctx *ctx, int which, const uint8_t *packed4, const uint64_t *byte_offsets,
+	const uint64_t *lengths, const float *weights, uint32_t n);
+
 int pcr_load_sequences(pcr_ctx *ctx, pcr_set which, const uint8_t *packed4, const uint64_t *byte_offsets,
 	const uint64_t *lengths, const float *weights, uint32_t n)
 {
-	if(!ctx || (which != PCR_SET_TARGET && which != PCR_SET_BACKGROUND) || (n && (!packed4 || !byte_offsets || !lengths))){
+	if(!set_ok(which)){ g_err = "pcr_load_sequences: unknown sequence set"; return PCR_ERR_ARG; }
+	return load_sequences_impl(ctx, (int)which, packed4, byte_offsets, lengths, weights, n);
+}
+
+// (which may be the internal scratch set)
+static int load_sequences_impl(pcr_ctx *ctx, int which, const uint8_t *packed4, const uint64_t *byte_offsets,
+	const uint64_t *lengths, const float *weights, uint32_t n)
+{
+	if(!ctx || which < 0 || which >= PCR_N_SETS || (n && (!packed4 || !byte_offsets || !lengths))){
 		g_err = "pcr_load_sequences: bad argument"; return PCR_ERR_ARG;
 	}
 	DRAIN(ctx);
@@ -1380,6 +1395,7 @@ int pcr_load_sequences(pcr_ctx *ctx, pcr_set which, const uint8_t *packed4, cons
 
 int pcr_set_active(pcr_ctx *ctx, pcr_set which, const uint8_t *active)
 {
+	if(!set_ok(which)){ g_err = "pcr_set_active: unknown sequence set"; return PCR_ERR_ARG; }
 	if(!ctx || !active){ g_err = "pcr_set_active: bad argument"; return PCR_ERR_ARG; }
 	DRAIN(ctx);
 	HIP_TRY(hipSetDevice(ctx->device));
@@ -1395,6 +1411,7 @@ int pcr_set_active(pcr_ctx *ctx, pcr_set which, const uint8_t *active)
 
 int pcr_split(pcr_ctx *ctx, pcr_set which, uint32_t seq, uint64_t pos)
 {
+	if(!set_ok(which)){ g_err = "pcr_split: unknown sequence set"; return PCR_ERR_ARG; }
 	if(!ctx){ g_err = "null ctx"; return PCR_ERR_ARG; }
 	DRAIN(ctx);
 	HIP_TRY(hipSetDevice(ctx->device));
@@ -2041,6 +2058,7 @@ extern "C" {
 int pcr_select_words(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_pairs, int optimize_5, int optimize_3,
 	float threshold, uint32_t min_oligo_length, uint64_t *n_entries_out)
 {
+	if(!set_ok(which)){ g_err = "pcr_select_words: unknown sequence set"; return PCR_ERR_ARG; }
 	if(!ctx || (n_pairs && !pairs)){ g_err = "pcr_select_words: bad argument"; return PCR_ERR_ARG; }
 	DRAIN(ctx);
 	return select_impl(ctx, which, pairs, n_pairs, optimize_5, optimize_3, threshold, min_oligo_length, n_entries_out, false);
@@ -2049,6 +2067,7 @@ int pcr_select_words(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_
 int pcr_screen_device(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_pairs, int optimize_5, int optimize_3,
 	float select_threshold, uint32_t min_oligo_length, const pcr_amplify_args *args, uint64_t *d_bits_fr, uint64_t *d_bits_rf)
 {
+	if(!set_ok(which)){ g_err = "pcr_screen_device: unknown sequence set"; return PCR_ERR_ARG; }
 	if(!ctx || !args || (n_pairs && (!pairs || !d_bits_fr || !d_bits_rf))){ g_err = "pcr_screen_device: bad argument"; return PCR_ERR_ARG; }
 	if(ctx->pending.size() + 2 >= pcr_ctx::MAIL_RING) DRAIN(ctx);     // the mailbox ring bounds how far the host may run ahead
 	const uint32_t seq0 = ctx->mail_seq;
@@ -2067,6 +2086,7 @@ int pcr_screen_device(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32
 
 int64_t pcr_get_entries(pcr_ctx *ctx, pcr_set which, pcr_entry *out, uint64_t cap)
 {
+	if(!set_ok(which)){ g_err = "pcr_get_entries: unknown sequence set"; return PCR_ERR_ARG; }
 	if(!ctx){ g_err = "null ctx"; return PCR_ERR_ARG; }
 	DRAIN(ctx);
 	SeqSet &S = ctx->sets[which];
@@ -2093,6 +2113,7 @@ int64_t pcr_get_entries(pcr_ctx *ctx, pcr_set which, pcr_entry *out, uint64_t ca
 int pcr_amplify_device(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_pairs, const pcr_amplify_args *args,
 	uint64_t *d_bits_fr, uint64_t *d_bits_rf)
 {
+	if(!set_ok(which)){ g_err = "pcr_amplify_device: unknown sequence set"; return PCR_ERR_ARG; }
 	if(!ctx || !args || (n_pairs && (!pairs || !d_bits_fr || !d_bits_rf))){ g_err = "pcr_amplify_device: bad argument"; return PCR_ERR_ARG; }
 	DRAIN(ctx);
 	HIP_TRY(hipSetDevice(ctx->device));
@@ -2102,6 +2123,7 @@ int pcr_amplify_device(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint3
 int pcr_amplify(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_pairs, const pcr_amplify_args *args,
 	uint64_t *bits, uint64_t *bits_fr, uint64_t *bits_rf, float *coverage)
 {
+	if(!set_ok(which)){ g_err = "pcr_amplify: unknown sequence set"; return PCR_ERR_ARG; }
 	if(!ctx || !args || (n_pairs && !pairs)){ g_err = "pcr_amplify: bad argument"; return PCR_ERR_ARG; }
 	DRAIN(ctx);
 	HIP_TRY(hipSetDevice(ctx->device));
@@ -2132,6 +2154,7 @@ int pcr_amplify(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 int pcr_move_coverage(pcr_ctx *ctx, pcr_set which, const pcr_pair *base, int side, const pcr_word128 *variants, uint32_t n_variants,
 	const pcr_amplify_args *args, uint64_t *bits_fr, uint64_t *bits_rf, float *coverage)
 {
+	if(!set_ok(which)){ g_err = "pcr_move_coverage: unknown sequence set"; return PCR_ERR_ARG; }
 	if(!ctx || !args || !base || (side != 0 && side != 1) || (n_variants && !variants)){ g_err = "pcr_move_coverage: bad argument"; return PCR_ERR_ARG; }
 	DRAIN(ctx);
 	HIP_TRY(hipSetDevice(ctx->device));
@@ -2347,4 +2370,5 @@ int64_t pcr_host_move_trials(const pcr_word128 *oligo, int move, double max_dege
 } // extern "C"
 
 #include "pcr_entry_sw_thermo.inc"
+#include "pcr_multiplex_screen.inc"
 #include "pcr_writers.inc"
