@@ -117,6 +117,29 @@ def test_many_candidates_and_duplicates(both, oracle):
     assert e3 == _oracle_entries(oracle, seqs, pairs, 1.0, 0.9, 1, 1)
 
 
+@pytest.mark.parametrize("n_pairs,lens", [(128, (18, 19)), (300, (18, 25))])
+def test_dense_seed_lists_are_demoted(both, oracle, n_pairs, lens):
+    """Select threshold 0.81 with hundreds of orientations: the seed lists outgrow the tables (128 pairs of 18-19-mers: 256
+    orientations x ~270 codes > 40 960 seeds for k_seed_tables, the longest lists go to the bit-sliced scan; 300 pairs = 1 200
+    orientations: host-built tables, > 32 768 distinct codes, a quarter of the orientations demoted per round) -- the word DB
+    must not depend on who scans what."""
+    rng = random.Random(4100 + n_pairs)
+    root = rand_seq(rng, 2400)
+    seqs = [root] + [mutate(rng, root, 0.04) for _ in range(5)] + [rand_seq(rng, 1200) for _ in range(2)]
+    pairs = []
+    for i in range(n_pairs):
+        a = rng.randrange(0, 2100)
+        f = root[a:a + rng.randint(*lens)]
+        r = revcomp(root[a + 110:a + 110 + rng.randint(*lens)])
+        pairs.append((oracle.centered_word(f), oracle.centered_word(r)))
+    thr = float(np.float32(0.9) * np.float32(0.9))
+    e3 = _entries(both[0], seqs, pairs, thr)
+    e2 = _entries(both[1], seqs, pairs, thr)
+    assert e3 == e2 and len(e3) > 100
+    if n_pairs == 128:
+        assert e3 == _oracle_entries(oracle, seqs, pairs, 0.9, 0.9)
+
+
 def test_iupac_both_sides(both, oracle):
     rng = random.Random(5)
     root = rand_seq(rng, 3000)
