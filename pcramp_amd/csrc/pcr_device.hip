@@ -624,7 +624,7 @@ struct pcr_ctx {
 	bool s2_attr_set = false; uint32_t s2_dbg = 0;
 	// first form, tables built on the device (k_seed_tables): the pass's seed list, its own per-oligo cache (8-gram seeds), the tables
 	std::vector<uint32_t> s1_seeds; std::unordered_map<S2Key, S2Entry, S2KeyHash> s1_cache;
-	DevBuf<uint32_t> s1_image, s1_heads, s1_multi;
+	DevBuf<uint32_t> s1_image, s1_heads, s1_multi, s1_part;
 	bool host_seed_tables = false;   // PCRAMP_SEED_TABLES=host: build them on the host as for passes with shift candidates (A/B)
 	DevBuf<Hit> hits;
 	DevBuf<uint64_t> bits_fr, bits_rf;
@@ -1221,7 +1221,7 @@ void pcr_destroy(pcr_ctx *ctx)
 	for(int s = 0;s < PCR_N_SETS;++s) ctx->sets[s].release();
 	ctx->best.release();
 	ctx->counters.release(); ctx->mask.release(); ctx->status.release(); ctx->hits.release();
-	ctx->s1_image.release(); ctx->s1_heads.release(); ctx->s1_multi.release();
+	ctx->s1_image.release(); ctx->s1_heads.release(); ctx->s1_multi.release(); ctx->s1_part.release();
 	ctx->bits_fr.release(); ctx->bits_rf.release(); ctx->arena.release(); ctx->fin_scratch.release();
 	for(auto &sl : ctx->stage){ if(sl.host) (void)hipHostFree(sl.host); if(sl.done) (void)hipEventDestroy(sl.done); }
 	if(ctx->mail) (void)hipHostFree(ctx->mail);
@@ -1820,7 +1820,7 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 		if(build_tables){
 			d_s1_seeds = st.put(ctx->s1_seeds.data(), ctx->s1_seeds.size());
 			if((rc = ctx->s1_image.ensure(SEED_IMAGE_WORDS)) != PCR_OK) return rc;
-			if((rc = ctx->s1_heads.ensure(S1_MAX_SEEDS)) != PCR_OK) return rc;
+			if((rc = ctx->s1_heads.ensure(2*(size_t)S1_MAX_SEEDS)) != PCR_OK) return rc;   // two words per distinct code
 			if((rc = ctx->s1_multi.ensure(S1_MAX_SEEDS)) != PCR_OK) return rc;
 			ST.image = ctx->s1_image.p; ST.heads = ctx->s1_heads.p; ST.multi = ctx->s1_multi.p; ST.flat = 1;
 		}
@@ -1839,8 +1839,11 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 		}
 		else if((rc = st.ship(S.ctrl.p, (8 + 2*(size_t)S.n)*sizeof(uint32_t), nullptr, 0, nullptr, 0, ctx->mail_seq + 1)) != PCR_OK) return rc;
 		if(build_tables){
-			hipLaunchKernelGGL(k_seed_tables, dim3(1), dim3(S1_BUILD_THREADS), 0, ctx->stream, d_s1_seeds, (uint32_t)ctx->s1_seeds.size(),
-				ctx->s1_image.p, ctx->s1_heads.p, ctx->s1_multi.p);
+			if((rc = ctx->s1_part.ensure(2*S1_GROUPS)) != PCR_OK) return rc;
+			hipLaunchKernelGGL(k_seed_tables<false>, dim3(S1_GROUPS), dim3(S1_BUILD_THREADS), 0, ctx->stream, d_s1_seeds, (uint32_t)ctx->s1_seeds.size(),
+				ctx->s1_part.p, ctx->s1_image.p, ctx->s1_heads.p, ctx->s1_multi.p);
+			hipLaunchKernelGGL(k_seed_tables<true>, dim3(S1_GROUPS), dim3(S1_BUILD_THREADS), 0, ctx->stream, d_s1_seeds, (uint32_t)ctx->s1_seeds.size(),
+				ctx->s1_part.p, ctx->s1_image.p, ctx->s1_heads.p, ctx->s1_multi.p);
 			HIP_TRY(hipGetLastError());
 		}
 	}
