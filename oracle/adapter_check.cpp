@@ -141,6 +141,60 @@ struct DeviceScreen {       // one per process (one GPU); not thread-safe, like 
 		for(size_t i = 0;i < trial.size();++i){ trial[i].oligo(FORWARD, W(p[i].f)); trial[i].oligo(REVERSE, W(p[i].r)); }
 	}
 
+	// main.cpp:697-735: optimize() of every trial assay of the design iteration, in lockstep on the device; trial[t] becomes
+	// the optimised assay, the returned Scores are optimize()'s (before the detailed background screening of :737-863)
+	std::vector<Score> optimize_trials(std::vector<PCR> &trial, const std::deque<PCR> &pool, const std::deque<int> &moves,
+		bool have_background, const Options &opt)
+	{
+		pcr_optimize_args o;
+		memset(&o, 0, sizeof(o));
+		o.max_degen = opt.degen; o.primer_min = opt.primer_range.first; o.primer_max = opt.primer_range.second;
+		o.thermo = thermo_args(opt);
+		const pcr_amplify_args ta = { opt.target_threshold*opt.target_search_multiplier, opt.target_threshold,
+			opt.target_amplicon_range.first, opt.target_amplicon_range.second, opt.use_taq_mama ? 1 : 0 };
+		const pcr_amplify_args ba = { opt.background_threshold*opt.background_search_multiplier, opt.background_threshold,
+			opt.background_amplicon_range.first, opt.background_amplicon_range.second, opt.use_taq_mama ? 1 : 0 };
+		o.target = ta; o.background = ba;
+		o.have_background = have_background ? 1 : 0;
+		o.use_multiplex = opt.use_multiplex ? 1 : 0; o.multiplex_threshold = opt.background_threshold;
+		o.n_moves = 0;
+		for(std::deque<int>::const_iterator m = moves.begin();m != moves.end() && o.n_moves < 8;++m) o.moves[o.n_moves++] = *m;
+		std::vector<pcr_pair> in(trial.size()), best(trial.size()), pp(pool.size());
+		for(size_t i = 0;i < trial.size();++i) in[i] = P(trial[i]);
+		for(size_t i = 0;i < pool.size();++i) pp[i] = P(pool[i]);
+		std::vector<float> sc(3*trial.size() + 3);
+		check(pcr_optimize_batch(ctx, in.data(), (uint32_t)in.size(), &o, pp.data(), (uint32_t)pp.size(), best.data(), sc.data(), NULL));
+		std::vector<Score> out(trial.size());
+		for(size_t i = 0;i < trial.size();++i){
+			trial[i].oligo(FORWARD, W(best[i].f)); trial[i].oligo(REVERSE, W(best[i].r));
+			out[i].target_coverage = sc[3*i]; out[i].background_coverage = sc[3*i + 1]; out[i].oligo_overlap = sc[3*i + 2];
+		}
+		return out;
+	}
+
+	// main.cpp:744-803 for every trial assay: compatible[t] (:748-752) and the two background terms (:767-771, :786-803); the
+	// loop over t then only applies `best_score < s` and `s.background_coverage <= opt.max_background_cover`
+	void multiplex_screen(const std::vector<PCR> &trial, const std::deque<PCR> &pool, const Options &opt,
+		std::vector<bool> &compatible, std::vector<float> &multiplex_cover, std::vector<float> &pool_cover)
+	{
+		pcr_multiplex_screen_args a;
+		memset(&a, 0, sizeof(a));
+		a.thermo = thermo_args(opt);
+		a.background_threshold = opt.background_threshold; a.use_taq_mama = opt.use_taq_mama ? 1 : 0;
+		a.target_threshold = opt.target_threshold;
+		a.amp_min = opt.target_amplicon_range.first; a.amp_max = opt.target_amplicon_range.second;
+		std::vector<pcr_pair> t(trial.size()), pp(pool.size());
+		for(size_t i = 0;i < trial.size();++i) t[i] = P(trial[i]);
+		for(size_t i = 0;i < pool.size();++i) pp[i] = P(pool[i]);
+		std::vector<uint8_t> ok(trial.size() + 1);
+		multiplex_cover.assign(trial.size() + 1, 0.0f); pool_cover.assign(trial.size() + 1, 0.0f);
+		check(pcr_multiplex_screen(ctx, t.data(), (uint32_t)t.size(), pp.data(), (uint32_t)pp.size(), &a, NULL, ok.data(),
+			multiplex_cover.data(), pool_cover.data()));
+		compatible.resize(trial.size());
+		for(size_t i = 0;i < trial.size();++i) compatible[i] = ok[i] != 0;
+		multiplex_cover.resize(trial.size()); pool_cover.resize(trial.size());
+	}
+
 	// main.cpp:950-1113 in text form through the ABI's writer (the deflines keep their '>')
 	std::string assay_text(const PCR &a, const std::deque<PCR> &pool)
 	{
@@ -174,5 +228,10 @@ extern "C" int adapter_check_touch(int run)
 	d.find_background_match(m, trial[0], opt);
 	const float c = d.target_coverage(trial[0], opt);
 	const std::vector<bool> ok = d.is_valid(std::vector<Word>(1, trial[0].oligo(FORWARD)), true, opt);
+	std::deque<int> moves(1, PCR_MOVE_TRIM5);
+	const std::vector<Score> sc = d.optimize_trials(trial, std::deque<PCR>(), moves, false, opt);
+	std::vector<bool> comp; std::vector<float> mc, pc;
+	d.multiplex_screen(trial, std::deque<PCR>(), opt, comp, mc, pc);
+	if(sc.size() != comp.size()) return -1;
 	return (int)c + (int)ok.size() + (int)d.assay_text(trial[0], std::deque<PCR>()).size();
 }
