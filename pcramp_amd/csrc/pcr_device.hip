@@ -10,21 +10,25 @@
 //   tb[]      : 2 bits per base (A,C,G,T = 0..3, anything else 0), 2 u32 per block: q-gram codes of the seed scan.
 //   valid[]   : one u32 per block; bit j = the 32-base window starting at 32*b+j is a REGULAR
 //               window that Sequence::pack emits (sequence.cpp:127-153 filters applied).
-//   irr[]     : explicit irregular words (pcr_host.hpp).
+//   irr[]     : explicit irregular words (pcr_host.hpp); irr_scan[]: the same in scan order as 2-bit codes (k_seed2).
+//   tile_desc[]: one 16-byte descriptor per 1024-window tile (k_seed2).
 // Kernels
-//   k_transpose, k_valid, k_tile_degen : load-time index build (replaces Sequence::operator= + the filter half of pack)
+//   k_transpose, k_valid, k_tile_degen, k_tile_desc : load-time index build (replaces Sequence::operator= + the filter half of pack)
 //   k_stage                : per-pass tables out of host-mapped memory + clearing of the pass's control block
-//   k_seed (+ scan_irr_block), k_scan2, k_scan, k_scan_irr :
-//                            oligo x window match counts + per-(sequence,candidate) running max
+//   k_seed2                : the default match scan: seed filter on 9-grams, tables built in LDS (pcr_scan_seed2.inc)
+//   k_seed (+ k_seed_tables, scan_irr_block), k_scan2, k_scan, k_scan_irr :
+//                            the other forms of the oligo x window match scan + per-(sequence,candidate) running max
 //                            (select_words.cpp:88-117 over the implicit word index); pcr_scan_seed.inc,
 //                            pcr_scan_bitsliced.inc
-//   k_touched, k_finalize  : per-sequence arg-max-with-ties filter, sort, dedupe -> the device word DB
-//                            (select_words.cpp:100-138)
+//   k_touched, k_finalize, k_post : per-sequence arg-max-with-ties filter, sort, dedupe -> the device word DB
+//                            (select_words.cpp:100-138); k_post = the whole tail of the fused pass in one launch
 //   k_match, k_pair        : match_words / find_oligo_match / find_amplicon_match / update_identity /
 //                            sqrtf(f*r) test (optimize.cpp:209-301, pcr_assay.cpp:12-69,338-441,544-578)
-//   k_pair_moves           : the same sweep for the trial words of a local-search move (optimize_pcr.cpp)
-//   k_sw, k_bg_*, k_mx_*   : SeqOverlap Smith-Waterman and the background / multiplex screens (pcr_sw.inc)
-//   thermo::k_thermo       : NucCruc (pcr_thermo.inc)
+//   k_pair_moves, k_pair_moves_batch : the same sweep for the trial words of a local-search move (optimize_pcr.cpp; pcr_optimize.inc)
+//   k_sw, k_sw_words, k_bg_*, k_mx_* : SeqOverlap Smith-Waterman and the background / multiplex screens (pcr_sw.inc)
+//   thermo::k_thermo_wave  : NucCruc (pcr_thermo.inc)
+// Host side in the same library: pcr_optimize.inc (optimize() batched over trial assays), pcr_sampler.inc, pcr_multiplex.inc,
+// pcr_multiplex_screen.inc, pcr_writers.inc.
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
