@@ -373,6 +373,34 @@ constexpr int FIN_WAVES = 8;          // one wave per sequence, 8 sequences per 
 constexpr uint32_t MAX_BUCKET_CAP = 8192;   // 8192 keys x 8 B = the 64 KB of LDS one wave may sort in
 
 
+// (seq_base: blk_off of the key's sequence, which callers that work on one sequence have loaded long before)
+__device__ __forceinline__ void materialise_entry_at(uint64_t k, const uint4 *__restrict__ planes, uint64_t seq_base,
+	const IrrDev *__restrict__ irr, const uint32_t *__restrict__ irr_off, DevEntry &e)
+{
+	const uint32_t seq = (uint32_t)(k >> KEY_SEQ_SHIFT);
+	const int32_t loc = (int32_t)(uint32_t)((k >> KEY_LOC_SHIFT) & 0xFFFFFFFFull) - LOC_BIAS;
+	const uint32_t strand = (uint32_t)((k >> 7) & 1) + 1;
+	const uint32_t kind = (uint32_t)((k >> 6) & 1), ord = (uint32_t)(k & 63);
+	e.loc = loc; e.seq = seq; e.strand = strand; e.pad = 0;
+	if(kind == 0){
+		const uint32_t p = (strand == 1) ? (uint32_t)loc : (uint32_t)(loc - 31);
+		const uint32_t b = p >> 5, sh = p & 31;
+		const uint4 lo = planes[seq_base + b];
+		const uint4 hi = planes[seq_base + b + 1];
+		const uint32_t a = funnel(lo.x, hi.x, sh), c = funnel(lo.y, hi.y, sh);
+		const uint32_t g = funnel(lo.z, hi.z, sh), t = funnel(lo.w, hi.w, sh);
+		if(strand == 1){ e.w.a = a; e.w.c = c; e.w.g = g; e.w.t = t; }
+		else{ e.w.a = __brev(t); e.w.t = __brev(a); e.w.c = __brev(g); e.w.g = __brev(c); }   // Word::complement, word.h:140
+	}
+	else{
+		e.w.a = e.w.c = e.w.g = e.w.t = 0;
+		for(uint32_t j = irr_off[seq];j < irr_off[seq + 1];++j){
+			const IrrDev r = irr[j];
+			if(r.loc == loc && (r.meta & 0xFF) == strand && ((r.meta >> 16) & 0xFF) == ord){ e.w = r.w; break; }
+		}
+	}
+}
+
 __device__ void materialise_entry(uint64_t k, const uint4 *__restrict__ planes, const uint64_t *__restrict__ blk_off,
 	const IrrDev *__restrict__ irr, const uint32_t *__restrict__ irr_off, DevEntry &e)
 {
