@@ -117,18 +117,18 @@ def test_bad_oligo_rejected(dev, oracle):
         dev.is_valid([(0, 0)])
 
 
-def test_both_kernel_forms_agree(dev, oracle):
-    """pcr_thermo / pcr_dimer pick the one-job-per-wave kernel for batches up to 20 480 jobs and the
-    64-jobs-per-wave kernel beyond: the same oligos through both (one big call vs. small calls) give the same
-    bits, and a sample of them equals the oracle."""
+def test_results_do_not_depend_on_the_batch(dev, oracle):
+    """One kernel form (a wave per job) serves every batch size; a big call differs from a small one in how the jobs reach it
+    (1 200 oligos: job records in the mapped input buffer, homodimer halves mirrored by the kernel; 24 000 oligos: 48 000
+    wave jobs, several per resident block): the same oligos give the same bits, and a sample of them equals the oracle."""
     rng = random.Random(88)
     seqs = []
     for _ in range(1200):
         n = rng.randint(12, 32)
         seqs.append(rand_seq(rng, n) if rng.random() < 0.7 else hairpin_prone(rng, n)[:32])
     words = [oracle.centered_word(s) for s in seqs]
-    small = dev.is_valid(words, True)                                  # 1 200 jobs: wave form
-    big = dev.is_valid(words * 20, True)                               # 24 000 jobs: 64-per-wave form
+    small = dev.is_valid(words, True)
+    big = dev.is_valid(words * 20, True)
     for k in range(20):
         assert big[k * 1200:(k + 1) * 1200] == small
     for s, r in list(zip(seqs, small))[::25]:
