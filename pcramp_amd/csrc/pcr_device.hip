@@ -42,6 +42,7 @@
 #include <chrono>
 #include <algorithm>
 #include <unordered_map>
+#include <type_traits>
 
 #include "../../include/pcramp_hip.h"
 #include "pcr_host.hpp"
