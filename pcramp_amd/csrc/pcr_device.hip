@@ -649,6 +649,7 @@ struct pcr_ctx {
 	bool force_seed1 = false;   // PCRAMP_SEED=1: the first form of the seed scan (A/B)
 	// second form of the seed scan: the pass's seed list, mask tables (reused between passes) and the per-oligo seed cache
 	std::vector<uint32_t> s2_seeds; std::vector<uint4> s2_masks; std::vector<uint8_t> s2_floors;
+	std::vector<uint32_t> s2_group_end, s2_group_offmask;   // the seed list in groups of whole orientations, each within one launch's LDS budget
 	struct S2Key { uint32_t a, c, g, t, floor_; bool operator==(const S2Key &o) const { return a == o.a && c == o.c && g == o.g && t == o.t && floor_ == o.floor_; } };
 	struct S2KeyHash { size_t operator()(const S2Key &k) const { uint64_t h = 0x9E3779B97F4A7C15ull; for(uint32_t v : {k.a, k.c, k.g, k.t, k.floor_}){ h ^= v; h *= 0x100000001B3ull; h ^= h >> 29; } return (size_t)h; } };
 	struct S2Entry { std::vector<uint32_t> seeds; /* code << 14 | off << 9 */ uint32_t off_mask; bool seedable; };
@@ -1485,14 +1486,19 @@ namespace {
 inline uint32_t spread16(uint32_t v) { uint32_t r = 0; for(int i = 0;i < 16;++i) r |= ((v >> i) & 1u) << (2*i); return r; }
 
 // The seeds of a pass for the second form of the seed scan: per orientation from the cache (derived on a miss), listed as
-// code << 14 | slot offset << 9 | orientation.  false: more than S2_MAX_SEEDS seeds (the first form takes the pass).
+// code << 14 | slot offset << 9 | orientation, in at most S2_MAX_GROUPS groups of whole orientations, each of which fits the
+// LDS budget of one launch (IUPAC primers expand to more 9-gram seeds than one launch holds: two launches of this form still
+// beat the first form, 2 x ~65 vs 178 + 22 us at C5's shard).  false: more than that (the first form takes the pass).
+constexpr uint32_t S2_MAX_GROUPS = 2;
 bool plan_seed2(pcr_ctx *ctx, const std::vector<pcrhost::Candidate> &cand, std::vector<uint32_t> &or_seed, std::vector<uint32_t> &or_plain, uint32_t &irr_off_mask)
 {
 	const uint32_t n_or = 2*(uint32_t)cand.size();
 	std::vector<uint32_t> &out = ctx->s2_seeds;
-	out.clear();
+	out.clear(); ctx->s2_group_end.clear(); ctx->s2_group_offmask.clear();
 	irr_off_mask = 0;
 	if(ctx->s2_cache.size() > 16384) ctx->s2_cache.clear();
+	size_t group_begin = 0; uint32_t group_mask = 0;
+	auto fits = [&](size_t n){ return n <= S2_MAX_SEEDS && sizeof(S2Shared) + 32*(size_t)n_or + 6*n + 512 <= 160*1024; };   // the tables of a launch must fit one CU's LDS
 	for(uint32_t o = 0;o < n_or;++o){
 		const pcrhost::Candidate &c = cand[o >> 1];
 		const Planes &m = (o & 1u) ? c.rc : c.fwd;
@@ -1509,13 +1515,17 @@ bool plan_seed2(pcr_ctx *ctx, const std::vector<pcrhost::Candidate> &cand, std::
 		const pcr_ctx::S2Entry &e = it->second;
 		if(!e.seedable){ or_plain.push_back(o); continue; }
 		or_seed.push_back(o);
-		if(out.size() + e.seeds.size() > S2_MAX_SEEDS) return false;
-		if(sizeof(S2Shared) + 32*(size_t)n_or + 6*(out.size() + e.seeds.size()) + 512 > 160*1024) return false;   // the tables of the pass must fit one CU's LDS
+		if(!fits(out.size() - group_begin + e.seeds.size())){               // close the group, open the next
+			if(!fits(e.seeds.size()) || ctx->s2_group_end.size() + 1 >= S2_MAX_GROUPS) return false;
+			ctx->s2_group_end.push_back((uint32_t)out.size()); ctx->s2_group_offmask.push_back(group_mask);
+			group_begin = out.size(); group_mask = 0;
+		}
 		const size_t at = out.size();
 		out.resize(at + e.seeds.size());
 		for(size_t k = 0;k < e.seeds.size();++k) out[at + k] = e.seeds[k] | o;
-		if(!(o & 1u)) irr_off_mask |= e.off_mask;                       // slot offsets at which forward seeds sit (irregular-word scan)
+		if(!(o & 1u)){ irr_off_mask |= e.off_mask; group_mask |= e.off_mask; }   // slot offsets at which forward seeds sit (irregular-word scan)
 	}
+	ctx->s2_group_end.push_back((uint32_t)out.size()); ctx->s2_group_offmask.push_back(group_mask);
 	return true;
 }
 
@@ -1919,21 +1929,31 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 			else{
 				if(need_plain && (rc = launch_scan2(ctx, S, tab_plain, ncand, sink, d_tab_plain, d_bias_plain, nullptr, S.n_tiles, d_map_plain)) != PCR_OK) return rc;
 				if(!or_seed.empty() && use_seed2){
-					const size_t dyn = 2*(size_t)n_or*sizeof(uint4) + (((size_t)n_or + 15) & ~size_t(15)) + 4*(size_t)ST2.n_seeds + 2*(((size_t)ST2.n_seeds + 1) & ~size_t(1)) + 16;
 					// persistent workgroups of 16 waves, one per CU (the tables they build take most of its LDS); the irregular words
-					// are taken by the same waves once their tiles are done
+					// are taken by the same waves once their tiles are done.  One launch per seed group (plan_seed2).
 					const uint32_t tiles_per_wg = S2_WAVES*2;
 					const dim3 sgrid(std::max<uint32_t>(1u, std::min<uint32_t>((S.n_tiles + tiles_per_wg - 1)/tiles_per_wg, ctx->n_cu))), sblock(S2_THREADS);
-					IrrArgs2 IA; IA.scan = S.irr_scan.p; IA.irr = S.irr.p; IA.n_live = n_live; IA.off_mask = or_plain.empty() ? irr_off_mask : 0u;
 					irr_fused = true;
-					if(getenv("PCRAMP_DEBUG")) fprintf(stderr, "[pcramp] k_seed2: %u workgroups, %u seeds, %zu + %zu B of LDS\n", sgrid.x, ST2.n_seeds, sizeof(S2Shared), dyn);
 					if(!ctx->s2_attr_set){
 						HIP_TRY(hipFuncSetAttribute((const void *)k_seed2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160*1024 - sizeof(S2Shared))));
 						ctx->s2_attr_set = true;
 					}
-					hipLaunchKernelGGL(k_seed2, sgrid, sblock, dyn, ctx->stream, S.tb.p, S.valid.p, S.tile_desc.p, S.n_tiles, ST2, S.d_active.p, ctx->d_cand_fwd, ctx->d_cand_floor, ncand, IA, sink,
-						ctx->s2_dbg);
-					HIP_TRY(hipGetLastError());
+					uint32_t g_begin = 0;
+					for(size_t g = 0;g < ctx->s2_group_end.size();++g){
+						Seed2Tables Tg = ST2;
+						Tg.seeds = ST2.seeds + g_begin; Tg.n_seeds = ctx->s2_group_end[g] - g_begin;
+						g_begin = ctx->s2_group_end[g];
+						if(Tg.n_seeds == 0) continue;
+						const size_t dyn = 2*(size_t)n_or*sizeof(uint4) + (((size_t)n_or + 15) & ~size_t(15)) + 4*(size_t)Tg.n_seeds + 2*(((size_t)Tg.n_seeds + 1) & ~size_t(1)) + 16;
+						IrrArgs2 IA; IA.scan = S.irr_scan.p; IA.irr = S.irr.p; IA.n_live = n_live;
+						IA.off_mask = ctx->s2_group_offmask[g];
+						IA.exhaustive = (g == 0) ? 1u : 0u;                                 // words holding IUPAC slots meet every candidate once, in the first launch
+						if(getenv("PCRAMP_DEBUG")) fprintf(stderr, "[pcramp] k_seed2: %u workgroups, %u seeds (group %zu of %zu), %zu + %zu B of LDS\n", sgrid.x, Tg.n_seeds, g + 1,
+							ctx->s2_group_end.size(), sizeof(S2Shared), dyn);
+						hipLaunchKernelGGL(k_seed2, sgrid, sblock, dyn, ctx->stream, S.tb.p, S.valid.p, S.tile_desc.p, S.n_tiles, Tg, S.d_active.p, ctx->d_cand_fwd, ctx->d_cand_floor, ncand, IA, sink,
+							ctx->s2_dbg);
+						HIP_TRY(hipGetLastError());
+					}
 					if(need_seedset && (rc = launch_scan2(ctx, S, tab_seedset, ncand, sink, d_tab_seedset, d_bias_seedset, S.degen_tiles.p,
 						S.n_degen_tiles, d_map_seedset)) != PCR_OK) return rc;
 				}
