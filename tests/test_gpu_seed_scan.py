@@ -7,7 +7,7 @@ import random
 import numpy as np
 import pytest
 
-from pcramp_amd import api
+from pcramp_amd import api, words as W
 from testdata import rand_seq, revcomp, mutate
 
 pytestmark = pytest.mark.gpu
@@ -163,6 +163,44 @@ def test_iupac_both_sides(both, oracle):
         e2 = _entries(both[1], seqs, pairs, thr)
         assert e3 == e2
         assert e3 == _oracle_entries(oracle, seqs, pairs, thr_t, 0.9)
+
+
+def test_iupac_primers_in_two_seed_groups(both, oracle):
+    """60 primer pairs (240 orientations) with 2-4 two-fold IUPAC positions each (C5's kind): their 9-gram seeds (> 12 288) do not fit one launch of the
+    second form, which then takes the pass in two groups of whole orientations; targets with IUPAC tiles and irregular words
+    holding IUPAC codes (those meet every candidate once, in the first launch)."""
+    rng = random.Random(505)
+    root = rand_seq(rng, 2600)
+    seqs = [root]
+    for i in range(5):
+        t = list(mutate(rng, root, 0.03))
+        for _ in range(2 * i):
+            t[rng.randrange(len(t))] = rng.choice("RYKMSWN")
+        if i == 4:
+            t[5] = "R"                                             # an IUPAC code inside the head partial words
+            t[len(t) - 7] = "Y"
+        seqs.append("".join(t))
+    seqs.append(rand_seq(rng, 900))
+    pairs = []
+    for i in range(60):
+        a = rng.randrange(0, 2300)
+        f, r = list(root[a:a + rng.randint(18, 25)]), list(revcomp(root[a + 110:a + 110 + rng.randint(18, 25)]))
+        for o in (f, r):
+            for _ in range(rng.randint(2, 4)):
+                o[rng.randrange(len(o))] = rng.choice("RYKMSW")
+        pairs.append((oracle.centered_word("".join(f)), oracle.centered_word("".join(r))))
+    thr = float(np.float32(1.0) * np.float32(0.9))
+    n9 = 0
+    for f, r in pairs:
+        for w in (f, r):
+            floor = int(np.float32(sum(1 for c in W.slots_from_word(w) if c)) * np.float32(thr))
+            sd = api.host_orientation_seeds(w, floor)
+            n9 += 2 * len(sd) if sd is not None else 0            # (8-gram lists; the 9-gram ones are longer)
+    assert n9 > 12288
+    e3 = _entries(both[0], seqs, pairs, thr)
+    e2 = _entries(both[1], seqs, pairs, thr)
+    assert e3 == e2 and len(e3) > 50
+    assert e3 == _oracle_entries(oracle, seqs, pairs, 1.0, 0.9)
 
 
 def test_dense_hits_low_complexity(both, oracle):
