@@ -43,6 +43,7 @@
 #include <algorithm>
 #include <unordered_map>
 #include <type_traits>
+#include <thread>
 
 #include "../../include/pcramp_hip.h"
 #include "pcr_host.hpp"
