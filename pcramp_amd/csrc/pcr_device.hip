@@ -267,6 +267,21 @@ __global__ void k_touched(const uint32_t *__restrict__ seq_count, uint32_t n, ui
 	if(has) touched[base + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull))] = s;
 }
 
+// the same list from the DB's segment ends (a sequence with hits has at least one entry), for DBs whose per-sequence fills
+// the fused tail has already zeroed
+__global__ void k_touched_seg(const uint32_t *__restrict__ seg_hi, uint32_t n, uint32_t *__restrict__ counters, uint32_t *__restrict__ touched)
+{
+	const uint32_t s = blockIdx.x*blockDim.x + threadIdx.x;
+	const bool has = s < n && seg_hi[s] != 0;
+	const uint64_t mask = __ballot(has);
+	if(!mask) return;
+	const uint32_t lane = threadIdx.x & 63u, leader = (uint32_t)__builtin_ctzll(mask);
+	uint32_t base = 0;
+	if(lane == leader) base = atomicAdd(&counters[3], (uint32_t)__builtin_popcountll(mask));
+	base = __shfl(base, leader);
+	if(has) touched[base + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull))] = s;
+}
+
 // v1 match scan: one lane = one window start; the window's four 32-bit plane slices live in
 // registers; candidates are wave-uniform (scalar loads), 4 and/or + popcount + compare each.
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan(
@@ -604,6 +619,8 @@ struct SeqSet {
 	std::vector<std::vector<pcrhost::IrrEntry> > irr_host;
 	uint64_t total_blocks = 0;
 	uint32_t n_tiles = 0, n_irr = 0;
+	bool ctrl_clean = false;     // the control block is all zero (the fused tail k_post leaves it so): the next fused pass need not clear it
+	bool touched_from_seg = false;   // the per-sequence fills were zeroed by k_post: the touched list comes from the segment ends
 	uint32_t bucket_cap = 64;   // hit slots per sequence of this set's word DB (grows on overflow; per set: the target DB at 0.9 needs 64, a background DB selected at 0.72 thousands)
 	DevBuf<uint32_t> irr_perm; uint32_t irr_size_count[256];   // irregular words by size counter, largest first
 	DevBuf<uint4> planes;
@@ -687,6 +704,11 @@ struct pcr_ctx {
 	struct StageSlot { uint8_t *host = nullptr, *dev = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool busy = false;
 	                   uint32_t guard_seq = 0; /* != 0: free once the pass with this mailbox sequence number has published */ };
 	StageSlot stage[STAGE_RING]; int stage_next = 0;
+	// The lean form of the fused pass needs no staging launch at all: its tables are written by the CPU straight into
+	// fine-grained DEVICE memory (large BAR: posted writes, ordered before the doorbell of the launch that follows; measured
+	// 0.6 us for 32 KB, profiles/microbench/bar_write.hip), a ring of its own because the kernels read the slot itself.
+	StageSlot dstage[STAGE_RING]; int dstage_next = 0;
+	bool direct_ok = false;       // fine-grained device memory can be had and written (probed in pcr_create; PCRAMP_STAGE=kernel turns it off)
 	typedef PassMail Mail;
 	static constexpr uint32_t MAIL_RING = 8;
 	Mail *mail = nullptr, *mail_dev = nullptr;   // host-mapped ring (slot = seq % MAIL_RING): k_publish writes it, the host spins on seq
@@ -876,9 +898,33 @@ int wait_published(pcr_ctx *ctx, uint32_t seq)
 }
 
 struct Stager {
-	pcr_ctx *ctx; size_t used = 0;
+	pcr_ctx *ctx; size_t used = 0; bool direct = false;
 	explicit Stager(pcr_ctx *c) : ctx(c) {}
 	pcr_ctx::StageSlot *slot = nullptr;
+	// direct: the bytes go straight into a slot of device memory (see pcr_ctx::dstage); the caller launches no k_stage for
+	// them and passes the sequence number of ITS pass to seal(): the slot is free again once the NEXT pass has published,
+	// i.e. once every kernel of this one is over.
+	int begin_direct(size_t bytes)
+	{
+		direct = true;
+		slot = &ctx->dstage[ctx->dstage_next];
+		ctx->dstage_next = (ctx->dstage_next + 1) % pcr_ctx::STAGE_RING;
+		if(slot->guard_seq){ const int grc = wait_published(ctx, slot->guard_seq); if(grc != PCR_OK) return grc; slot->guard_seq = 0; }
+		if(bytes + 256 > slot->cap){
+			if(slot->dev){ HIP_TRY(hipStreamSynchronize(ctx->stream)); (void)hipFree(slot->dev); slot->dev = slot->host = nullptr; slot->cap = 0; }
+			const size_t want = std::max<size_t>((bytes + 256)*2, 1 << 17);
+			HIP_TRY(hipExtMallocWithFlags((void **)&slot->dev, want, hipDeviceMallocFinegrained));
+			slot->host = slot->dev;                                  // one address for the CPU's stores and the kernels' loads
+			slot->cap = want;
+		}
+		used = 0;
+		return PCR_OK;
+	}
+	void seal(uint32_t pass_seq)
+	{
+		__builtin_ia32_sfence();                                     // the write-combined stores leave the core before the doorbell is rung
+		slot->guard_seq = pass_seq + 1;
+	}
 	int begin(size_t bytes)
 	{
 		slot = &ctx->stage[ctx->stage_next];
@@ -902,7 +948,7 @@ struct Stager {
 	{
 		used = (used + 15) & ~size_t(15);
 		memcpy(slot->host + used, src, n*sizeof(T));
-		T *dev = (T *)(ctx->arena.p + used);
+		T *dev = (T *)((direct ? slot->dev : ctx->arena.p) + used);
 		used += n*sizeof(T);
 		return dev;
 	}
@@ -1057,7 +1103,8 @@ void build_oligos(const pcr_pair *pairs, uint32_t n_pairs, const pcr_amplify_arg
 int ensure_touched(pcr_ctx *ctx, SeqSet &S)
 {
 	if(S.touched_built || !S.have_db || !S.ctrl.p) return PCR_OK;
-	hipLaunchKernelGGL(k_touched, dim3((S.n + 255)/256), dim3(256), 0, ctx->stream, S.ctrl.p + 8, S.n, S.ctrl.p, S.touched.p);
+	if(S.touched_from_seg) hipLaunchKernelGGL(k_touched_seg, dim3((S.n + 255)/256), dim3(256), 0, ctx->stream, S.d_seg_hi, S.n, S.ctrl.p, S.touched.p);
+	else hipLaunchKernelGGL(k_touched, dim3((S.n + 255)/256), dim3(256), 0, ctx->stream, S.ctrl.p + 8, S.n, S.ctrl.p, S.touched.p);
 	HIP_TRY(hipGetLastError());
 	uint32_t n = 0;
 	HIP_TRY(hipMemcpyAsync(&n, S.ctrl.p + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -1218,6 +1265,19 @@ pcr_ctx *pcr_create(int device, void *hip_stream, const pcr_params *params)
 	if(const char *v = getenv("PCRAMP_SEED_TABLES")) ctx->host_seed_tables = v[0] == 'h';
 	if(const char *v = getenv("PCRAMP_S2DBG")) ctx->s2_dbg = (uint32_t)atoi(v);
 	if(const char *v = getenv("PCRAMP_SCAN")){ if(v[0] == '1') ctx->scan_version = 1; else if(v[0] == '2') ctx->scan_version = 2; }   // A/B: 1 = popcount scan, 2 = bit-sliced only
+	{
+		// direct staging: can fine-grained device memory be allocated (a large-BAR system lets the CPU store into it)?
+		const char *v = getenv("PCRAMP_STAGE");
+		if(!(v && v[0] == 'k')){
+			void *probe = nullptr;
+			if(hipExtMallocWithFlags(&probe, 4096, hipDeviceMallocFinegrained) == hipSuccess && probe){
+				hipPointerAttribute_t at;
+				ctx->direct_ok = hipPointerGetAttributes(&at, probe) == hipSuccess;
+				(void)hipFree(probe);
+			}
+			else (void)hipGetLastError();
+		}
+	}
 	ctx->filt.max_degen = ctx->params.pack_max_degen;
 	ctx->filt.set_gc(ctx->params.pack_min_gc, ctx->params.pack_max_gc);
 	if(hipMemcpyToSymbol(HIP_SYMBOL(c_taq_mama), h_taq_mama, sizeof(h_taq_mama)) != hipSuccess ||
@@ -1259,6 +1319,7 @@ void pcr_destroy(pcr_ctx *ctx)
 	ctx->s1_image.release(); ctx->s1_heads.release(); ctx->s1_multi.release(); ctx->s1_part.release();
 	ctx->bits_fr.release(); ctx->bits_rf.release(); ctx->arena.release(); ctx->fin_scratch.release();
 	for(auto &sl : ctx->stage){ if(sl.host) (void)hipHostFree(sl.host); if(sl.done) (void)hipEventDestroy(sl.done); }
+	for(auto &sl : ctx->dstage){ if(sl.dev) (void)hipFree(sl.dev); }
 	if(ctx->mail) (void)hipHostFree(ctx->mail);
 	if(ctx->ret_host) (void)hipHostFree(ctx->ret_host);
 	if(ctx->in_host) (void)hipHostFree(ctx->in_host);
@@ -1313,6 +1374,7 @@ static int load_sequences_impl(pcr_ctx *ctx, int which, const uint8_t *packed4, 
 	S.weight.assign(n, 1.0f);
 	if(weights) S.weight.assign(weights, weights + n);
 	S.weight_dirty = true;
+	S.ctrl_clean = false; S.touched_from_seg = false;
 	S.active.assign(n, 1);
 	S.has_eos.assign(n, 0);
 	S.blk_off.assign(n + 1, 0);
@@ -1745,6 +1807,9 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 	SeqSet &S = ctx->sets[which];
 	S.have_db = false; S.n_entries = 0;
 	if(n_entries_out) *n_entries_out = 0;
+	const bool ctrl_was_clean = S.ctrl_clean;         // left so by the fused tail of the previous pass over this set
+	S.ctrl_clean = false; S.touched_from_seg = false;
+	bool lean = false, cleared_bits = false; size_t lean_bits_bytes = 0;   // lean: the fused pass without a staging launch (see pcr_ctx::dstage)
 	HostTimer timer(ctx, 0);
 	if(ctx->timing) ++ctx->n_timed;
 	std::vector<pcrhost::Candidate> cand;
@@ -1837,8 +1902,17 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 			if(fuse){ build_oligos(fa->pairs, fa->n_pairs, fa->a, ol); bytes += ol.size()*sizeof(OligoDev) + 64; }
 		}
 		timer.next(1);
+		// the pass's control block (counters | per-sequence fills | segment ends)
+		{
+			const uint64_t gen = S.ctrl.generation;
+			if((rc = S.ctrl.ensure(8 + 2*(size_t)S.n + 4)) != PCR_OK) return rc;
+			lean = ctx->direct_ok && async && fuse && use_seed2 && !or_seed.empty() && ctrl_was_clean && gen == S.ctrl.generation
+				&& S.bucket_cap == POST_CAP && 2*fa->n_pairs <= 32*POST_MASK_WORDS;
+			lean_bits_bytes = bits_bytes;
+		}
+		if(getenv("PCRAMP_DEBUG")) fprintf(stderr, "[pcramp] staging: %s\n", lean ? "lean (tables written into device memory, no staging launch)" : "k_stage");
 		Stager st(ctx);
-		if((rc = st.begin(bytes)) != PCR_OK) return rc;
+		if((rc = lean ? st.begin_direct(bytes) : st.begin(bytes)) != PCR_OK) return rc;
 		ctx->d_cand_fwd = st.put(hf.data(), ncand);
 		ctx->d_cand_rc = st.put(hr.data(), ncand);
 		ctx->d_cand_floor = st.put(hfl.data(), ncand);
@@ -1874,12 +1948,13 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 			ST2.floors = st.put(floors2.data(), floors2.size());
 			ST2.n_seeds = (uint32_t)ctx->s2_seeds.size(); ST2.n_or = n_or;
 		}
-		// the same launch clears the pass's control block (counters | per-sequence fills | segment ends)
-		if((rc = S.ctrl.ensure(8 + 2*(size_t)S.n + 4)) != PCR_OK) return rc;
+		// the staging launch also clears the control block and the result bitsets -- unless the pass is lean: then the tables
+		// are already in device memory, the control block was left clean by the previous pass's tail and k_seed2 clears the bitsets
 		if(fuse){
 			fa->d_oligos = st.put(ol.data(), ol.size());
 			fa->staged = true;
-			if((rc = st.ship(S.ctrl.p, (8 + 2*(size_t)S.n)*sizeof(uint32_t), fa->d_fr, bits_bytes, fa->d_rf, bits_bytes, ctx->mail_seq + 1)) != PCR_OK) return rc;
+			if(lean) st.seal(ctx->mail_seq + 1);
+			else if((rc = st.ship(S.ctrl.p, (8 + 2*(size_t)S.n)*sizeof(uint32_t), fa->d_fr, bits_bytes, fa->d_rf, bits_bytes, ctx->mail_seq + 1)) != PCR_OK) return rc;
 		}
 		else if((rc = st.ship(S.ctrl.p, (8 + 2*(size_t)S.n)*sizeof(uint32_t), nullptr, 0, nullptr, 0, ctx->mail_seq + 1)) != PCR_OK) return rc;
 		if(build_tables){
@@ -1951,8 +2026,13 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 						IA.exhaustive = (g == 0) ? 1u : 0u;                                 // words holding IUPAC slots meet every candidate once, in the first launch
 						if(getenv("PCRAMP_DEBUG")) fprintf(stderr, "[pcramp] k_seed2: %u workgroups, %u seeds (group %zu of %zu), %zu + %zu B of LDS\n", sgrid.x, Tg.n_seeds, g + 1,
 							ctx->s2_group_end.size(), sizeof(S2Shared), dyn);
+						S2Clear Z = { nullptr, 0u, nullptr, 0u };
+						if(lean && !cleared_bits){                                           // the first launch of a lean pass clears the result bitsets
+							Z.z0 = (uint4 *)fa->d_fr; Z.z1 = (uint4 *)fa->d_rf; Z.n0 = Z.n1 = (uint32_t)(lean_bits_bytes/16);
+							cleared_bits = true;
+						}
 						hipLaunchKernelGGL(k_seed2, sgrid, sblock, dyn, ctx->stream, S.tb.p, S.valid.p, S.tile_desc.p, S.n_tiles, Tg, S.d_active.p, ctx->d_cand_fwd, ctx->d_cand_floor, ncand, IA, sink,
-							ctx->s2_dbg);
+							ctx->s2_dbg, Z);
 						HIP_TRY(hipGetLastError());
 					}
 					if(need_seedset && (rc = launch_scan2(ctx, S, tab_seedset, ncand, sink, d_tab_seedset, d_bias_seedset, S.degen_tiles.p,
@@ -2008,7 +2088,10 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 #define POST_ARGS ctx->hits.p, d_seq_count, ctx->best.p, ncand, S.planes.p, S.d_blk_off.p, S.irr.p, S.irr_off.p, S.db.p, S.d_seg_hi, d_counters, ctx->epoch, S.n, \
 	fa->d_oligos, fa->n_pairs, (2*fa->n_pairs + 31)/32, S.d_len.p, S.d_active.p, fa->a->amp_min, fa->a->amp_max, \
 	fa->a->ident_threshold, fa->a->use_taq_mama, fa->d_fr, fa->d_rf, bw, ctx->mail_dev + (ctx->mail_seq % pcr_ctx::MAIL_RING), ctx->mail_seq
-			if(cap == POST_CAP) hipLaunchKernelGGL(k_post, dim3((S.n + POST_WAVES - 1)/POST_WAVES), dim3(64*POST_WAVES), 0, ctx->stream, POST_ARGS);
+			if(cap == POST_CAP){
+				hipLaunchKernelGGL(k_post, dim3((S.n + POST_WAVES - 1)/POST_WAVES), dim3(64*POST_WAVES), 0, ctx->stream, POST_ARGS);
+				S.ctrl_clean = true; S.touched_from_seg = true;              // k_post zeroes the counters and fills it has read
+			}
 			else if(cap == 128) hipLaunchKernelGGL((k_post_big<128, 4>), dim3((S.n + 3)/4), dim3(256), 0, ctx->stream, POST_ARGS);
 			else hipLaunchKernelGGL((k_post_big<256, 4>), dim3((S.n + 3)/4), dim3(256), 0, ctx->stream, POST_ARGS);
 #undef POST_ARGS

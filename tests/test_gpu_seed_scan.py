@@ -279,6 +279,58 @@ def test_screen_device_equals_separate_calls(both, oracle):
         assert np.array_equal(got[1], w[1])
 
 
+def test_lean_passes_leave_a_consistent_state(oracle):
+    """From the second fused pass over a set on, the pass is 'lean': no staging launch (tables written into device memory by the
+    host, control block left clean by the previous pass's tail, result bitsets cleared by the scan).  Batches that hit different
+    families alternate, so sequences with entries in one pass have none in the next; after every pass the word DB, the bits
+    of a synchronous amplify over that DB (touched list rebuilt from the segment ends) and the amplicons equal what the
+    synchronous path gives for the same batch."""
+    import torch
+    rng = random.Random(77031)
+    roots = [rand_seq(rng, 2400) for _ in range(3)]
+    seqs = []
+    for r in roots:
+        seqs += [r] + [mutate(rng, r, 0.03) for _ in range(12)]
+    seqs += [rand_seq(rng, 1500) for _ in range(4)]
+    def batch(root, k):
+        out = []
+        for i in range(k):
+            a = rng.randrange(0, 2000)
+            out.append((oracle.centered_word(root[a:a + rng.randint(18, 25)]), oracle.centered_word(revcomp(root[a + 100:a + 100 + rng.randint(18, 25)]))))
+        return out
+    # (even batch sizes: with 43 sequences a pair's bitset is 8 bytes, and the fused tail wants 16-byte multiples; the odd batch
+    # at the end takes the unfused route in between, after which the next pass is not lean either)
+    batches = [batch(roots[0], 6), batch(roots[1], 4), batch(roots[2], 8), batch(roots[0], 4) + batch(roots[2], 4), batch(roots[1], 2), batch(roots[1], 3)]
+    thr_t = 1.0
+    thr = float(np.float32(thr_t) * np.float32(0.9))
+    ref = _screener(None)                       # synchronous path, for the expected state of every batch
+    dev = _screener(None)
+    try:
+        ref.load_texts(seqs, [1.0] * len(seqs))
+        dev.load_texts(seqs, [1.0] * len(seqs))
+        words = int(dev.bitset_words())
+        for k, p in enumerate(batches * 2):     # twelve passes: the first and those around an odd batch are not lean, the others are
+            want_fr, want_rf = _bits_sync(ref, p, thr, thr_t)
+            want_entries = ref.entries()
+            o = torch.full((2, len(p), words), -1, dtype=torch.int64, device="cuda:0")
+            dev.screen_device(p, thr, o[0].data_ptr(), o[1].data_ptr(), thr_t, thr_t, 80, 200, False)
+            dev.synchronize()
+            torch.cuda.synchronize()
+            got = _to_bool(o, len(seqs))
+            assert np.array_equal(got[0], want_fr) and np.array_equal(got[1], want_rf), k
+            assert dev.entries() == want_entries, k                        # no entry of an earlier pass survives
+            _, fr, rf, _ = dev.amplify(p, thr_t, thr_t, 80, 200, False)    # touched list from the segment ends
+            assert np.array_equal(np.array(fr), want_fr) and np.array_equal(np.array(rf), want_rf), k
+            if k % 3 == 1:
+                a1 = dev.collect_amplicons(p[0], thr_t, 80, 200)
+                a2 = ref.collect_amplicons(p[0], thr_t, 80, 200)
+                assert a1 == a2, k
+        assert any(len(b) for b in batches)
+    finally:
+        ref.close()
+        dev.close()
+
+
 def test_screen_device_replays_after_bucket_overflow(oracle):
     """A pass whose per-sequence buckets overflow is detected at synchronize() and replayed: same bits as the
     synchronous path (which retries inside pcr_select_words)."""
