@@ -179,6 +179,12 @@ int pcr_profile_read_kernel(pcr_ctx *ctx, int kernel, double *ms, uint64_t *laun
 /* Blocks until the handle's stream is idle. */
 int pcr_synchronize(pcr_ctx *ctx);
 
+/* How the small per-pass tables of pcr_screen_device reach the device (reported by bench.py): 1 = "lean" -- the CPU
+ * stores them straight into fine-grained device memory (large BAR; probed by pcr_create with a store / fence / kernel
+ * read-back round trip) and the pass has no staging launch; 0 = a staging kernel (k_stage) copies them out of mapped
+ * host memory (PCRAMP_STAGE=kernel, no large BAR, or a failed probe). */
+int pcr_staging_mode(pcr_ctx *ctx);
+
 
 /* ---- Smith-Waterman primer x template alignment (rows a7/a8 of the scope table) */
 

@@ -164,6 +164,7 @@ def load_library():
     L.pcr_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
     L.pcr_profile_read_kernel.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
     L.pcr_synchronize.argtypes = [C.c_void_p]
+    L.pcr_staging_mode.argtypes = [C.c_void_p]
     L.pcr_sw_align_words.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     L.pcr_background_match.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.POINTER(BackgroundArgs), C.c_void_p]
     L.pcr_multiplex_match.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_float, C.c_int, C.c_void_p]
@@ -709,6 +710,10 @@ class Screener:
         n = C.c_uint64(0)
         self._check(self.L.pcr_profile_read_kernel(self.h, int(kernel), C.byref(ms), C.byref(n), int(reset)))
         return ms.value, n.value
+
+    def staging_mode(self):
+        """'lean' (the CPU stores the per-pass tables straight into device memory, no staging launch) or 'k_stage'."""
+        return "lean" if self.L.pcr_staging_mode(self.h) else "k_stage"
 
     def synchronize(self):
         self._check(self.L.pcr_synchronize(self.h))

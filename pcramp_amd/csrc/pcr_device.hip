@@ -619,7 +619,7 @@ struct SeqSet {
 	std::vector<std::vector<pcrhost::IrrEntry> > irr_host;
 	uint64_t total_blocks = 0;
 	uint32_t n_tiles = 0, n_irr = 0;
-	bool ctrl_clean = false;     // the control block is all zero (the fused tail k_post leaves it so): the next fused pass need not clear it
+	bool ctrl_clean = false;     // counters[0], counters[2], the per-sequence fills and the segment ends of sequences without hits are zero (the fused tail k_post leaves them so; counters[1] and [3] may be set by k_post / k_touched*: the lean k_seed2 zeroes those two itself): the next fused pass need not clear the block
 	bool touched_from_seg = false;   // the per-sequence fills were zeroed by k_post: the touched list comes from the segment ends
 	uint32_t bucket_cap = 64;   // hit slots per sequence of this set's word DB (grows on overflow; per set: the target DB at 0.9 needs 64, a background DB selected at 0.72 thousands)
 	DevBuf<uint32_t> irr_perm; uint32_t irr_size_count[256];   // irregular words by size counter, largest first
@@ -667,7 +667,7 @@ struct pcr_ctx {
 	bool force_seed1 = false;   // PCRAMP_SEED=1: the first form of the seed scan (A/B)
 	// second form of the seed scan: the pass's seed list, mask tables (reused between passes) and the per-oligo seed cache
 	std::vector<uint32_t> s2_seeds; std::vector<uint4> s2_masks; std::vector<uint8_t> s2_floors;
-	std::vector<uint32_t> s2_group_end, s2_group_offmask;   // the seed list in groups of whole orientations, each within one launch's LDS budget
+	std::vector<uint32_t> s2_group_end, s2_group_offmask, s2_group_or, s2_group_nor;   // per group: end in the seed list, forward-seed slot offsets, first orientation, orientations spanned   // the seed list in groups of whole orientations, each within one launch's LDS budget
 	struct S2Key { uint32_t a, c, g, t, floor_; bool operator==(const S2Key &o) const { return a == o.a && c == o.c && g == o.g && t == o.t && floor_ == o.floor_; } };
 	struct S2KeyHash { size_t operator()(const S2Key &k) const { uint64_t h = 0x9E3779B97F4A7C15ull; for(uint32_t v : {k.a, k.c, k.g, k.t, k.floor_}){ h ^= v; h *= 0x100000001B3ull; h ^= h >> 29; } return (size_t)h; } };
 	struct S2Entry { std::vector<uint32_t> seeds; /* code << 14 | off << 9 */ uint32_t off_mask; bool seedable; };
@@ -696,6 +696,7 @@ struct pcr_ctx {
 	std::vector<uint16_t> seed_count; std::vector<uint8_t> seed_fill, seed_own;   // host scratch of the seed-table builder
 	uint32_t epoch = 0;         // pass counter tagging best[] (see HitSink)
 	uint32_t debug_epoch = 0;   // PCRAMP_DEBUG_EPOCH: value the counter takes when best[] is first cleared
+	uint32_t opt_dbg_wg_tasks = 0, opt_dbg_task_cap = 0;   // PCRAMP_DEBUG_OPT_TASKS=<per workgroup>,<global>: shrink k_pair_moves_batch's task lists so that their overflow branches run (tests)
 	uint64_t best_seen = 0;      // generation of best[] that has been cleared (the allocator may hand the same address back: never compare pointers)
 	// pinned staging for the small per-call host->device payload (candidates, tables, oligos): one async copy
 	// ring of host-mapped staging buffers: a slot is rewritten only after the k_stage that read it has run,
@@ -1261,21 +1262,38 @@ pcr_ctx *pcr_create(int device, void *hip_stream, const pcr_params *params)
 	{ hipDeviceProp_t prop; if(hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->n_cu = (uint32_t)prop.multiProcessorCount; }
 	if(const char *v = getenv("PCRAMP_TIMING")) ctx->timing = v[0] == '1';
 	if(const char *v = getenv("PCRAMP_DEBUG_EPOCH")) ctx->debug_epoch = (uint32_t)strtoul(v, nullptr, 0);   // test hook: start the pass counter near its wrap
+	if(const char *v = getenv("PCRAMP_DEBUG_OPT_TASKS")){ unsigned a = 0, b = 0; if(sscanf(v, "%u,%u", &a, &b) >= 1){ ctx->opt_dbg_wg_tasks = a; ctx->opt_dbg_task_cap = b; } }
 	if(const char *v = getenv("PCRAMP_SEED")) ctx->force_seed1 = v[0] == '1';
 	if(const char *v = getenv("PCRAMP_SEED_TABLES")) ctx->host_seed_tables = v[0] == 'h';
 	if(const char *v = getenv("PCRAMP_S2DBG")) ctx->s2_dbg = (uint32_t)atoi(v);
 	if(const char *v = getenv("PCRAMP_SCAN")){ if(v[0] == '1') ctx->scan_version = 1; else if(v[0] == '2') ctx->scan_version = 2; }   // A/B: 1 = popcount scan, 2 = bit-sliced only
 	{
-		// direct staging: can fine-grained device memory be allocated (a large-BAR system lets the CPU store into it)?
+		// direct staging: fine-grained device memory the CPU can store into (large BAR) and whose stores a later launch sees.
+		// Probed, not assumed: the device must report a large BAR (otherwise a CPU store into the allocation would fault), and a
+		// pattern stored by the CPU, fenced, must come back through a kernel that copies it into mapped host memory.
 		const char *v = getenv("PCRAMP_STAGE");
-		if(!(v && v[0] == 'k')){
-			void *probe = nullptr;
-			if(hipExtMallocWithFlags(&probe, 4096, hipDeviceMallocFinegrained) == hipSuccess && probe){
+		if(!(v && v[0] == 'k') && prop.isLargeBar){
+			void *probe = nullptr; uint32_t *back = nullptr, *back_dev = nullptr;
+			constexpr uint32_t PROBE_WORDS = 1024;
+			if(hipExtMallocWithFlags(&probe, PROBE_WORDS*sizeof(uint32_t), hipDeviceMallocFinegrained) == hipSuccess && probe &&
+			   hipHostMalloc((void **)&back, PROBE_WORDS*sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess && back &&
+			   hipHostGetDevicePointer((void **)&back_dev, back, 0) == hipSuccess){
 				hipPointerAttribute_t at;
-				ctx->direct_ok = hipPointerGetAttributes(&at, probe) == hipSuccess;
-				(void)hipFree(probe);
+				bool ok = hipPointerGetAttributes(&at, probe) == hipSuccess;
+				for(int round = 0;ok && round < 2;++round){
+					volatile uint32_t *w = (volatile uint32_t *)probe;
+					for(uint32_t i = 0;i < PROBE_WORDS;++i){ w[i] = 0x9E3779B9u*(i + 1) + (uint32_t)round; back[i] = 0; }
+					__builtin_ia32_sfence();
+					hipLaunchKernelGGL(k_stage, dim3(1), dim3(256), 0, ctx->stream, (const uint4 *)probe, (uint4 *)back_dev, PROBE_WORDS/4,
+						(uint4 *)nullptr, 0u, (uint4 *)nullptr, 0u, (uint4 *)nullptr, 0u);
+					ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
+					for(uint32_t i = 0;ok && i < PROBE_WORDS;++i) ok = back[i] == 0x9E3779B9u*(i + 1) + (uint32_t)round;
+				}
+				ctx->direct_ok = ok;
 			}
 			else (void)hipGetLastError();
+			if(probe) (void)hipFree(probe);
+			if(back) (void)hipHostFree(back);
 		}
 	}
 	ctx->filt.max_degen = ctx->params.pack_max_degen;
@@ -1333,6 +1351,8 @@ void pcr_destroy(pcr_ctx *ctx)
 
 uint32_t pcr_num_sequences(pcr_ctx *ctx, pcr_set which) { return (ctx && set_ok(which)) ? ctx->sets[which].n : 0; }
 uint64_t pcr_bitset_words(pcr_ctx *ctx, pcr_set which) { return (ctx && set_ok(which)) ? (ctx->sets[which].n + 63)/64 : 0; }
+
+int pcr_staging_mode(pcr_ctx *ctx) { return (ctx && ctx->direct_ok) ? 1 : 0; }
 
 int pcr_synchronize(pcr_ctx *ctx)
 {
@@ -1549,19 +1569,21 @@ namespace {
 inline uint32_t spread16(uint32_t v) { uint32_t r = 0; for(int i = 0;i < 16;++i) r |= ((v >> i) & 1u) << (2*i); return r; }
 
 // The seeds of a pass for the second form of the seed scan: per orientation from the cache (derived on a miss), listed as
-// code << 14 | slot offset << 9 | orientation, in at most S2_MAX_GROUPS groups of whole orientations, each of which fits the
-// LDS budget of one launch (IUPAC primers expand to more 9-gram seeds than one launch holds: two launches of this form still
-// beat the first form, 2 x ~65 vs 178 + 22 us at C5's shard).  false: more than that (the first form takes the pass).
-constexpr uint32_t S2_MAX_GROUPS = 2;
+// code << 14 | slot offset << 9 | orientation WITHIN ITS GROUP, in groups of at most S2_MAX_OR whole orientations, each of which
+// fits the LDS budget of one launch.  One launch per group: IUPAC primers expand to more 9-gram seeds than one launch holds
+// (two launches of this form still beat the first form, 2 x ~65 vs 178 + 22 us at C5's shard), and the reference's default
+// batch of 1 000 trial assays (pcramp.h:32) is 4 000 orientations = 16+ groups (r02 sent it to the first form with host-built
+// tables: 21 ms per select_words on a C5 shard).  false: an orientation whose seeds alone exceed one launch.
+constexpr uint32_t S2_MAX_GROUPS = 4096;
 bool plan_seed2(pcr_ctx *ctx, const std::vector<pcrhost::Candidate> &cand, std::vector<uint32_t> &or_seed, std::vector<uint32_t> &or_plain, uint32_t &irr_off_mask)
 {
 	const uint32_t n_or = 2*(uint32_t)cand.size();
 	std::vector<uint32_t> &out = ctx->s2_seeds;
-	out.clear(); ctx->s2_group_end.clear(); ctx->s2_group_offmask.clear();
+	out.clear(); ctx->s2_group_end.clear(); ctx->s2_group_offmask.clear(); ctx->s2_group_or.clear(); ctx->s2_group_nor.clear();
 	irr_off_mask = 0;
 	if(ctx->s2_cache.size() > 16384) ctx->s2_cache.clear();
-	size_t group_begin = 0; uint32_t group_mask = 0;
-	auto fits = [&](size_t n){ return n <= S2_MAX_SEEDS && sizeof(S2Shared) + 32*(size_t)n_or + 6*n + 512 <= 160*1024; };   // the tables of a launch must fit one CU's LDS
+	size_t group_begin = 0; uint32_t group_mask = 0, group_or0 = 0, group_last = 0;
+	auto fits = [&](size_t n, uint32_t g_or){ return g_or <= S2_MAX_OR && n <= S2_MAX_SEEDS && sizeof(S2Shared) + 32*(size_t)g_or + 6*n + 512 <= 160*1024; };   // the tables of a launch must fit one CU's LDS
 	for(uint32_t o = 0;o < n_or;++o){
 		const pcrhost::Candidate &c = cand[o >> 1];
 		const Planes &m = (o & 1u) ? c.rc : c.fwd;
@@ -1578,17 +1600,20 @@ bool plan_seed2(pcr_ctx *ctx, const std::vector<pcrhost::Candidate> &cand, std::
 		const pcr_ctx::S2Entry &e = it->second;
 		if(!e.seedable){ or_plain.push_back(o); continue; }
 		or_seed.push_back(o);
-		if(!fits(out.size() - group_begin + e.seeds.size())){               // close the group, open the next
-			if(!fits(e.seeds.size()) || ctx->s2_group_end.size() + 1 >= S2_MAX_GROUPS) return false;
-			ctx->s2_group_end.push_back((uint32_t)out.size()); ctx->s2_group_offmask.push_back(group_mask);
-			group_begin = out.size(); group_mask = 0;
+		// the group spans orientations [group_or0, o]: unseedable ones in between only take an (unused) id
+		if(!fits(out.size() - group_begin + e.seeds.size(), o - group_or0 + 1)){   // close the group, open the next at this orientation
+			if(!fits(e.seeds.size(), 1) || ctx->s2_group_end.size() + 1 >= S2_MAX_GROUPS) return false;
+			ctx->s2_group_end.push_back((uint32_t)out.size()); ctx->s2_group_offmask.push_back(group_mask); ctx->s2_group_or.push_back(group_or0); ctx->s2_group_nor.push_back(group_last - group_or0 + 1);
+			group_begin = out.size(); group_mask = 0; group_or0 = o;
 		}
+		group_last = o;
 		const size_t at = out.size();
 		out.resize(at + e.seeds.size());
-		for(size_t k = 0;k < e.seeds.size();++k) out[at + k] = e.seeds[k] | o;
+		for(size_t k = 0;k < e.seeds.size();++k) out[at + k] = e.seeds[k] | (o - group_or0);
 		if(!(o & 1u)){ irr_off_mask |= e.off_mask; group_mask |= e.off_mask; }   // slot offsets at which forward seeds sit (irregular-word scan)
 	}
-	ctx->s2_group_end.push_back((uint32_t)out.size()); ctx->s2_group_offmask.push_back(group_mask);
+	ctx->s2_group_end.push_back((uint32_t)out.size()); ctx->s2_group_offmask.push_back(group_mask); ctx->s2_group_or.push_back(group_or0);
+	ctx->s2_group_nor.push_back(or_seed.empty() ? 0u : group_last - group_or0 + 1);
 	return true;
 }
 
@@ -1840,11 +1865,12 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 	// the orientations and their 9-gram seeds fit its LDS budget; the host then only LISTS the seeds (from a cache keyed by
 	// oligo and floor: between two optimiser iterations most oligos stay what they were).
 	bool use_seed2 = false;
-	if(ctx->scan_version == 3 && !ctx->force_seed1 && !optimize_5 && !optimize_3 && n_or <= S2_MAX_OR){
+	if(ctx->scan_version == 3 && !ctx->force_seed1 && !optimize_5 && !optimize_3 && n_or <= 65535){
 		use_seed2 = plan_seed2(ctx, cand, or_seed, or_plain, irr_off_mask);
 		// an orientation without a 9-gram structure (low thresholds: k = 4 mismatching slots and more) may still have an 8-gram
-		// one: let the first form plan the pass, it hands fewer orientations to the bit-sliced scan
-		if(use_seed2 && !or_plain.empty()) use_seed2 = false;
+		// one: let the first form plan the pass where it can (it hands fewer orientations to the bit-sliced scan); a batch beyond
+		// its S1_MAX_OR orientations keeps this form for the seedable orientations, the others go to the bit-sliced scan
+		if(use_seed2 && !or_plain.empty() && (n_or <= S1_MAX_OR || or_seed.empty())) use_seed2 = false;
 		if(!use_seed2){ or_seed.clear(); or_plain.clear(); irr_off_mask = 0; }
 	}
 	bool dev_tables = false;                           // first form, tables built by k_seed_tables
@@ -2015,25 +2041,33 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 						ctx->s2_attr_set = true;
 					}
 					uint32_t g_begin = 0;
+					bool first_launch = true;
 					for(size_t g = 0;g < ctx->s2_group_end.size();++g){
 						Seed2Tables Tg = ST2;
+						const uint32_t or0 = ctx->s2_group_or[g], g_or = ctx->s2_group_nor[g];
 						Tg.seeds = ST2.seeds + g_begin; Tg.n_seeds = ctx->s2_group_end[g] - g_begin;
+						Tg.masks = ST2.masks + 2*(size_t)or0; Tg.floors = ST2.floors + or0; Tg.n_or = g_or; Tg.or_base = or0;
 						g_begin = ctx->s2_group_end[g];
 						if(Tg.n_seeds == 0) continue;
-						const size_t dyn = 2*(size_t)n_or*sizeof(uint4) + (((size_t)n_or + 15) & ~size_t(15)) + 4*(size_t)Tg.n_seeds + 2*(((size_t)Tg.n_seeds + 1) & ~size_t(1)) + 16;
+						const size_t dyn = 2*(size_t)g_or*sizeof(uint4) + (((size_t)g_or + 15) & ~size_t(15)) + 4*(size_t)Tg.n_seeds + 2*(((size_t)Tg.n_seeds + 1) & ~size_t(1)) + 16;
 						IrrArgs2 IA; IA.scan = S.irr_scan.p; IA.irr = S.irr.p; IA.n_live = n_live;
 						IA.off_mask = ctx->s2_group_offmask[g];
-						IA.exhaustive = (g == 0) ? 1u : 0u;                                 // words holding IUPAC slots meet every candidate once, in the first launch
-						if(getenv("PCRAMP_DEBUG")) fprintf(stderr, "[pcramp] k_seed2: %u workgroups, %u seeds (group %zu of %zu), %zu + %zu B of LDS\n", sgrid.x, Tg.n_seeds, g + 1,
-							ctx->s2_group_end.size(), sizeof(S2Shared), dyn);
-						S2Clear Z = { nullptr, 0u, nullptr, 0u };
+						IA.exhaustive = first_launch ? 1u : 0u;                             // words holding IUPAC slots meet every candidate once, in the first launch
+						if(!or_plain.empty()){                                              // unseeded candidates in the pass: every irregular word meets every candidate, once
+							IA.off_mask = 0;
+							if(!first_launch) IA.n_live = 0;
+						}
+						if(getenv("PCRAMP_DEBUG")) fprintf(stderr, "[pcramp] k_seed2: %u workgroups, %u seeds of orientations %u..%u (group %zu of %zu), %zu + %zu B of LDS\n", sgrid.x, Tg.n_seeds,
+							or0, or0 + g_or - 1, g + 1, ctx->s2_group_end.size(), sizeof(S2Shared), dyn);
+						S2Clear Z = { nullptr, 0u, nullptr, 0u, nullptr };
 						if(lean && !cleared_bits){                                           // the first launch of a lean pass clears the result bitsets
-							Z.z0 = (uint4 *)fa->d_fr; Z.z1 = (uint4 *)fa->d_rf; Z.n0 = Z.n1 = (uint32_t)(lean_bits_bytes/16);
+							Z.z0 = (uint4 *)fa->d_fr; Z.z1 = (uint4 *)fa->d_rf; Z.n0 = Z.n1 = (uint32_t)(lean_bits_bytes/16); Z.ctrl = d_counters;
 							cleared_bits = true;
 						}
 						hipLaunchKernelGGL(k_seed2, sgrid, sblock, dyn, ctx->stream, S.tb.p, S.valid.p, S.tile_desc.p, S.n_tiles, Tg, S.d_active.p, ctx->d_cand_fwd, ctx->d_cand_floor, ncand, IA, sink,
 							ctx->s2_dbg, Z);
 						HIP_TRY(hipGetLastError());
+						first_launch = false;
 					}
 					if(need_seedset && (rc = launch_scan2(ctx, S, tab_seedset, ncand, sink, d_tab_seedset, d_bias_seedset, S.degen_tiles.p,
 						S.n_degen_tiles, d_map_seedset)) != PCR_OK) return rc;

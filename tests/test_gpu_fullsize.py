@@ -2,7 +2,8 @@
 oracle (which would take hours here) -- the seed scan and the bit-sliced scan build the same word DB and
 amplification bits, the fused asynchronous pass equals the separate calls, evaluation is independent per
 target (a shard screened alone gives the same bits for its targets), a pass is idempotent, and the
-coverage checksum is the weighted popcount of the bits.  Run on the GPU box with `-m gpu`."""
+coverage checksum is the weighted popcount of the bits; the oracle itself screens a sample of the same workload, to which
+the full-size bits are tied.  Run on the GPU box with `-m gpu`."""
 import os
 
 import numpy as np
@@ -47,8 +48,9 @@ def _screen(d, wl, lo=0, hi=None, thr_t=1.0, mult=0.9):
     return n, fr, rf, cov
 
 
-def test_full_c2_properties(c2):
+def test_full_c2_properties(c2, oracle):
     import torch
+    from test_gpu_configs import _sample, _check_targets_against_oracle
     a, b, s1, s1h = _screener(None), _screener(2), _screener(None, seed_form=1), _screener(None, seed_form=1, tables="host")
     try:
         n3, fr3, rf3, cov3 = _screen(a, c2)
@@ -66,6 +68,10 @@ def test_full_c2_properties(c2):
         assert n1h == n3 and s1h.entries() == a.entries()
         s1h.close()
         assert fr3.any() or rf3.any()
+        # the tie to the CPU oracle (as for C3 / C4 / C5 in test_gpu_configs.py): a sample of the same workload -- the targets the
+        # first pairs were cut from plus family mates -- equals the oracle bit for bit (word DB, bits, coverage), and the full-size
+        # bits restricted to the sample equal the sample screened alone
+        _check_targets_against_oracle(oracle, c2, _sample(c2), fr3, rf3)
         # idempotence
         n3b, fr3b, rf3b, cov3b = _screen(a, c2)
         assert n3b == n3 and np.array_equal(fr3b, fr3) and np.array_equal(rf3b, rf3) and np.array_equal(cov3b, cov3)
