@@ -84,11 +84,14 @@ def cpu_baseline(wl, thr_t, mult, budget_s=12.0):
         if host > cores:
             legs.append(host)                  # every host thread of the box (the reference parallelises inside select_words only)
     for threads in legs:
-        # calibrate on 16 targets, then size the sample to the budget (the first targets of the workload)
-        n_cal = min(16, wl["T"])
+        # calibrate on 16 targets (4 for the all-threads leg: a GPU box grants its process a CPU share of 16 cores while
+        # sched_getaffinity lists every hardware thread, so that leg can be heavily oversubscribed), then size the sample to the
+        # budget (the first targets of the workload); a leg whose calibration is already slower than a finished leg stays there
+        n_cal = min(16 if threads <= cores else 4, wl["T"])
         dt = run(n_cal, threads)
         n_big = int(max(n_cal, min(wl["T"], 0.5 * budget_s / max(dt / n_cal, 1e-9))))
-        if n_big > n_cal:
+        slower = any(n_cal * len(wl["pairs"]) / dt < 0.5 * v[0] for v in out.values())
+        if n_big > n_cal and not slower:
             dt = run(n_big, threads)
             n_cal = n_big
         out[threads] = (n_cal * len(wl["pairs"]) / dt, n_cal, dt)
