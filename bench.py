@@ -415,6 +415,9 @@ def main():
     ap.add_argument("--random-primers", action="store_true", help="diagnostic: primers unrelated to the targets (no hits)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--gather-every", type=int, default=16, help="N>1: passes per all-gather (their bitsets travel in one collective)")
+    ap.add_argument("--exchange", choices=["torch", "abi"], default="torch",
+                    help="N>1: the all-gather through torch.distributed (async, on RCCL's stream) or through the C-ABI's pcr_exchange_bits "
+                         "(ncclAllGather enqueued on the handle's stream; what a C++ host would call)")
     ap.add_argument("--optimize-shifts", action="store_true",
                     help="diagnostic: --optimize.5/--optimize.3 of the reference (every 5'/3' slot shift of every oligo is a candidate)")
     ap.add_argument("--separate-calls", action="store_true",
@@ -501,6 +504,19 @@ def main():
     if world == 1 and not strong:
         wl_single = sets[0].block(0)
     NS = len(scrs)
+    comm = None
+    if use_dist and args.exchange == "abi" and not rehearsal:
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)                                     # (RCCL's banner goes to file descriptor 1)
+        try:
+            obj = [api.Screener.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(obj, src=0)        # the 128 bytes travel however the host likes (the reference: MPI_Bcast)
+            comm = scrs[0].comm_init_rank(obj[0], world, rank)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
 
     # The exchange is batched and pipelined: K passes write their bitsets into the K slices of one buffer, one all-gather
     # ships the batch (a torch collective costs the host ~100 us, a pass ~130 us of GPU time), and it runs on RCCL's
@@ -523,6 +539,8 @@ def main():
         with torch.cuda.stream(stream_obj):
             if rehearsal:
                 dist.all_gather_into_tensor(gathered[b].view(-1), local[b].cpu().view(-1))
+            elif comm is not None:
+                scrs[0].exchange_bits(comm, local[b].data_ptr(), local[b].numel(), gathered[b].data_ptr())
             else:
                 works[b] = dist.all_gather_into_tensor(gathered[b].view(-1), local[b].view(-1), async_op=True)
 
@@ -678,7 +696,8 @@ def main():
                                    % (shape, P, select_thr, thr_t),
                        "targets_this_gpu": T_local, "targets_total": T_total, "target_len": L, "pairs": P,
                        "sharding": "shard_ranges: contiguous target blocks, boundaries multiples of 64, x%d" % world,
-                       "exchange": ("all_gather_into_tensor of [%d passes, 2, P, words] u64 per rank, pipelined; handles drained before each gather" % K) if use_dist else "none",
+                       "exchange": ((("pcr_exchange_bits (ncclAllGather behind the C-ABI, on the handle's stream)" if comm is not None else "all_gather_into_tensor, pipelined")
+                                     + " of [%d passes, 2, P, words] u64 per rank; handles drained before each gather" % K) if use_dist else "none"),
                        "sharded_equals_unsharded": verify,
                        "timed_region_s": dt, "timed_blocks": len(block_dts), "timed_total_s": float(sum(block_dts)),
                        "block_ms_min_median_max": [min(block_dts) * 1e3, dt * 1e3, max(block_dts) * 1e3],

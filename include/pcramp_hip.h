@@ -185,6 +185,30 @@ int pcr_synchronize(pcr_ctx *ctx);
  * host memory (PCRAMP_STAGE=kernel, no large BAR, or a failed probe). */
 int pcr_staging_mode(pcr_ctx *ctx);
 
+/* ---- multi-GPU: the path's one exchange step.  Targets shard across ranks (one process per GPU,
+ * contiguous blocks whose boundaries are multiples of 64 sequences, so every rank owns whole bitset words); the primer pairs are
+ * replicated; after a pass every rank needs every rank's orientation bitsets.  This replaces what the reference's MPI mode does
+ * with its per-rank best assay -- Send/Recv of the BitSets to rank 0 and MPI_Bcast of the winner (main.cpp:1421-1601; wire
+ * format mpi_util.cpp:152-233) -- by ONE ncclAllGather over xGMI, enqueued on the handle's stream (no host hop, no torch).
+ *   pcr_comm_unique_id   rank 0: 128 opaque bytes (RCCL's ncclUniqueId) to hand to every rank (the reference's MPI_Bcast, a file, ...)
+ *   pcr_comm_init_rank   every rank, once: joins the communicator with this handle's device (any handle on that device may then
+ *                        exchange through it); NULL + pcr_last_error() on failure
+ *   pcr_exchange_bits    every rank, per pass: all-gather of words_per_rank u64 from d_local (device) into d_full (device,
+ *                        world x words_per_rank, rank-major).  Waits on the host only for the counters of passes pcr_screen_device
+ *                        enqueued (a bucket overflow replays a pass into the same buffers), then enqueues the collective; the
+ *                        result is complete after pcr_synchronize / in stream order for later kernels on the handle's stream.
+ * Coverage is then pcr_coverage_from_bits on every rank over the gathered words, in the reference's summation order.
+ * RCCL is bound at run time (the copy already loaded in the process first; PCRAMP_RCCL=<path> overrides). */
+#define PCR_COMM_ID_BYTES 128
+typedef struct pcr_comm pcr_comm;
+int pcr_comm_unique_id(uint8_t id[PCR_COMM_ID_BYTES]);
+pcr_comm *pcr_comm_init_rank(pcr_ctx *ctx, const uint8_t id[PCR_COMM_ID_BYTES], int world, int rank);
+int pcr_comm_world(const pcr_comm *comm);
+int pcr_comm_rank(const pcr_comm *comm);
+int pcr_exchange_bits(pcr_ctx *ctx, pcr_comm *comm, const uint64_t *d_local, uint64_t words_per_rank, uint64_t *d_full);
+void pcr_comm_destroy(pcr_comm *comm);
+const char *pcr_comm_library(void);      /* which librccl was bound ("" before the first use / when none was found) */
+
 
 /* ---- Smith-Waterman primer x template alignment (rows a7/a8 of the scope table) */
 

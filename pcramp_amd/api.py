@@ -116,7 +116,8 @@ ABI_SYMBOLS = [
     "pcr_random_assays", "pcr_host_rand_r", "pcr_host_max_overlap", "pcr_host_oligo_overlap", "pcr_host_pool_overlaps",
     "pcr_multiplex_load", "pcr_multiplex_coverage", "pcr_collect_amplicons",
     "pcr_format_oligos", "pcr_format_header", "pcr_format_iteration", "pcr_format_assay", "pcr_format_footer",
-    "pcr_optimize_batch", "pcr_optimization_move",
+    "pcr_optimize_batch", "pcr_optimization_move", "pcr_staging_mode",
+    "pcr_comm_unique_id", "pcr_comm_init_rank", "pcr_comm_world", "pcr_comm_rank", "pcr_exchange_bits", "pcr_comm_destroy", "pcr_comm_library",
 ]
 
 
@@ -165,6 +166,15 @@ def load_library():
     L.pcr_profile_read_kernel.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
     L.pcr_synchronize.argtypes = [C.c_void_p]
     L.pcr_staging_mode.argtypes = [C.c_void_p]
+    L.pcr_comm_unique_id.argtypes = [C.c_void_p]
+    L.pcr_comm_init_rank.restype = C.c_void_p
+    L.pcr_comm_init_rank.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    L.pcr_comm_world.argtypes = [C.c_void_p]
+    L.pcr_comm_rank.argtypes = [C.c_void_p]
+    L.pcr_exchange_bits.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    L.pcr_comm_destroy.argtypes = [C.c_void_p]
+    L.pcr_comm_destroy.restype = None
+    L.pcr_comm_library.restype = C.c_char_p
     L.pcr_sw_align_words.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     L.pcr_background_match.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.POINTER(BackgroundArgs), C.c_void_p]
     L.pcr_multiplex_match.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_float, C.c_int, C.c_void_p]
@@ -710,6 +720,30 @@ class Screener:
         n = C.c_uint64(0)
         self._check(self.L.pcr_profile_read_kernel(self.h, int(kernel), C.byref(ms), C.byref(n), int(reset)))
         return ms.value, n.value
+
+    # ---- the bitset exchange behind the ABI (RCCL all-gather on this handle's stream; include/pcramp_hip.h)
+    @staticmethod
+    def comm_unique_id():
+        """Rank 0: the 128 opaque bytes every rank passes to comm_init_rank."""
+        L = load_library()
+        buf = (C.c_uint8 * 128)()
+        if L.pcr_comm_unique_id(buf) != 0:
+            raise PcrError(_err(L))
+        return bytes(buf)
+
+    def comm_init_rank(self, unique_id, world, rank):
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        h = self.L.pcr_comm_init_rank(self.h, buf, int(world), int(rank))
+        if not h:
+            raise PcrError(_err(self.L))
+        return h
+
+    def exchange_bits(self, comm, d_local_ptr, words_per_rank, d_full_ptr):
+        """ncclAllGather of words_per_rank u64 per rank into d_full [world, words_per_rank] (device pointers), in stream order."""
+        self._check(self.L.pcr_exchange_bits(self.h, comm, int(d_local_ptr), int(words_per_rank), int(d_full_ptr)))
+
+    def comm_destroy(self, comm):
+        self.L.pcr_comm_destroy(comm)
 
     def staging_mode(self):
         """'lean' (the CPU stores the per-pass tables straight into device memory, no staging launch) or 'k_stage'."""

@@ -28,7 +28,7 @@
 //   k_sw, k_sw_words, k_bg_*, k_mx_* : SeqOverlap Smith-Waterman and the background / multiplex screens (pcr_sw.inc)
 //   thermo::k_thermo_wave  : NucCruc (pcr_thermo.inc)
 // Host side in the same library: pcr_optimize.inc (optimize() batched over trial assays), pcr_sampler.inc, pcr_multiplex.inc,
-// pcr_multiplex_screen.inc, pcr_writers.inc.
+// pcr_multiplex_screen.inc, pcr_writers.inc; pcr_exchange.inc: the bitset all-gather over RCCL.
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
@@ -2546,3 +2546,4 @@ int64_t pcr_host_move_trials(const pcr_word128 *oligo, int move, double max_dege
 #include "pcr_entry_sw_thermo.inc"
 #include "pcr_multiplex_screen.inc"
 #include "pcr_writers.inc"
+#include "pcr_exchange.inc"
