@@ -625,6 +625,9 @@ struct SeqSet {
 	DevBuf<uint32_t> irr_perm; uint32_t irr_size_count[256];   // irregular words by size counter, largest first
 	DevBuf<uint4> planes;
 	DevBuf<uint32_t> valid, nib, tb, blk_seq, tile_seq, tile_pos0, irr_off, degen_tiles;
+	// valid[] and tb[] carry zero padding in front and behind (k_seed2's tile fetch has no bounds checks, pcr_scan_seed2.inc): the DATA start here
+	uint32_t *valid_d() const { return valid.p + S2_VALID_FRONT; }
+	uint32_t *tb_d() const { return tb.p + S2_TB_FRONT; }
 	DevBuf<uint8_t> tile_degen; uint32_t n_degen_tiles = 0;
 	DevBuf<TileDesc> tile_desc;   // one per tile, with the sequence's active flag folded in (k_tile_desc; refreshed by pcr_set_active)
 	DevBuf<uint64_t> d_len, d_blk_off, d_nblk_real;
@@ -838,7 +841,7 @@ int run_valid(pcr_ctx *ctx, SeqSet &S, uint64_t first_block, uint64_t n_blocks)
 	const unsigned threads = 256;
 	const unsigned grid = (unsigned)((n_blocks + threads - 1)/threads);
 	hipLaunchKernelGGL(k_valid, dim3(grid), dim3(threads), 0, ctx->stream, S.planes.p, S.d_blk_off.p, S.blk_seq.p,
-		S.d_nblk_real.p, S.valid.p, S.total_blocks, ctx->filt.max_degen, ctx->filt.gc_ok, first_block, n_blocks);
+		S.d_nblk_real.p, S.valid_d(), S.total_blocks, ctx->filt.max_degen, ctx->filt.gc_ok, first_block, n_blocks);
 	HIP_TRY(hipGetLastError());
 	return PCR_OK;
 }
@@ -1175,7 +1178,7 @@ template<int NSLOT, int KLO>
 int launch_scan2_nw(pcr_ctx *ctx, SeqSet &S, uint32_t nw, uint32_t group0, uint32_t n_groups, uint32_t ncand, const HitSink &sink,
 	const uint32_t *d_tab, const uint32_t *d_bias, const uint32_t *tile_ids, uint32_t n_tiles, const uint32_t *orient_ids)
 {
-#define SCAN2_ARGS S.nib.p, S.planes.p, S.valid.p, S.d_blk_off.p, S.d_len.p, S.d_active.p, S.tile_seq.p, S.tile_pos0.p, \
+#define SCAN2_ARGS S.nib.p, S.planes.p, S.valid_d(), S.d_blk_off.p, S.d_len.p, S.d_active.p, S.tile_seq.p, S.tile_pos0.p, \
 	d_tab, d_bias, group0, tile_ids, orient_ids, ctx->d_cand_fwd, ctx->d_cand_rc, ctx->d_cand_floor, ncand, sink
 	const dim3 grid(n_tiles, n_groups), block(SCAN2_THREADS);
 	switch(nw){
@@ -1448,9 +1451,9 @@ static int load_sequences_impl(pcr_ctx *ctx, int which, const uint8_t *packed4, 
 	if((rc = d_byte_off.ensure(n)) != PCR_OK){ d_packed.release(); return rc; }
 	auto fail = [&](int code){ d_packed.release(); d_byte_off.release(); return code; };
 	if((rc = S.planes.ensure(total_blocks)) != PCR_OK) return fail(rc);
-	if((rc = S.valid.ensure(total_blocks)) != PCR_OK) return fail(rc);
+	if((rc = S.valid.ensure(S2_VALID_FRONT + total_blocks + S2_TAIL_BLOCKS)) != PCR_OK) return fail(rc);
 	if((rc = S.nib.ensure(total_blocks*4 + 8)) != PCR_OK) return fail(rc);
-	if((rc = S.tb.ensure(total_blocks*2 + 8)) != PCR_OK) return fail(rc);
+	if((rc = S.tb.ensure(S2_TB_FRONT + (total_blocks + S2_TAIL_BLOCKS)*2 + 8)) != PCR_OK) return fail(rc);
 	if((rc = S.tile_degen.ensure(n_tiles + 1)) != PCR_OK) return fail(rc);
 	if((rc = S.degen_tiles.ensure(n_tiles + 1)) != PCR_OK) return fail(rc);
 	if((rc = S.blk_seq.ensure(total_blocks)) != PCR_OK) return fail(rc);
@@ -1478,11 +1481,18 @@ static int load_sequences_impl(pcr_ctx *ctx, int which, const uint8_t *packed4, 
 	H2D(S.d_active.p, S.active.data(), n);
 	H2D(S.d_has_eos.p, S.has_eos.data(), n);
 #undef H2D
+	{   // the padding in front of and behind valid[] / tb[] (what k_seed2's unchecked tile fetch may touch beyond the sequences)
+		hipError_t e_ = hipMemsetAsync(S.valid.p, 0, S2_VALID_FRONT*sizeof(uint32_t), ctx->stream);
+		if(e_ == hipSuccess) e_ = hipMemsetAsync(S.valid_d() + total_blocks, 0, S2_TAIL_BLOCKS*sizeof(uint32_t), ctx->stream);
+		if(e_ == hipSuccess) e_ = hipMemsetAsync(S.tb.p, 0, S2_TB_FRONT*sizeof(uint32_t), ctx->stream);
+		if(e_ == hipSuccess) e_ = hipMemsetAsync(S.tb_d() + total_blocks*2, 0, (S2_TAIL_BLOCKS*2 + 8)*sizeof(uint32_t), ctx->stream);
+		if(e_ != hipSuccess){ g_err = std::string("load: padding memset: ") + hipGetErrorString(e_); return fail(PCR_ERR_DEVICE); }
+	}
 	if(total_blocks){
 		const unsigned threads = 256;
 		const unsigned grid = (unsigned)((total_blocks + threads - 1)/threads);
 		hipLaunchKernelGGL(k_transpose, dim3(grid), dim3(threads), 0, ctx->stream, d_packed.p, d_byte_off.p, S.d_len.p,
-			S.d_blk_off.p, S.blk_seq.p, S.planes.p, S.nib.p, S.tb.p, total_blocks);
+			S.d_blk_off.p, S.blk_seq.p, S.planes.p, S.nib.p, S.tb_d(), total_blocks);
 		if(hipGetLastError() != hipSuccess){ g_err = "k_transpose launch failed"; return fail(PCR_ERR_DEVICE); }
 		if((rc = run_valid(ctx, S, 0, total_blocks)) != PCR_OK) return fail(rc);
 	}
@@ -1583,7 +1593,7 @@ bool plan_seed2(pcr_ctx *ctx, const std::vector<pcrhost::Candidate> &cand, std::
 	irr_off_mask = 0;
 	if(ctx->s2_cache.size() > 16384) ctx->s2_cache.clear();
 	size_t group_begin = 0; uint32_t group_mask = 0, group_or0 = 0, group_last = 0;
-	auto fits = [&](size_t n, uint32_t g_or){ return g_or <= S2_MAX_OR && n <= S2_MAX_SEEDS && sizeof(S2Shared) + 32*(size_t)g_or + 6*n + 512 <= 160*1024; };   // the tables of a launch must fit one CU's LDS
+	auto fits = [&](size_t n, uint32_t g_or){ return g_or <= S2_MAX_OR && n <= S2_MAX_SEEDS && sizeof(S2Shared) + 32*(size_t)g_or + 8*n + 1024 <= 160*1024; };   // the tables of a launch must fit one CU's LDS
 	for(uint32_t o = 0;o < n_or;++o){
 		const pcrhost::Candidate &c = cand[o >> 1];
 		const Planes &m = (o & 1u) ? c.rc : c.fwd;
@@ -2023,7 +2033,7 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 			// events around the scan launches of every prof_stride-th pass (an event between two kernels costs a ~6 us queue bubble)
 			ProfScope scan_prof(ctx, PCR_PROF_SCAN, ctx->prof && (ctx->prof_pass++ % ctx->prof_stride) == 0);
 			if(ctx->scan_version == 1){
-				hipLaunchKernelGGL(k_scan, dim3(S.n_tiles), dim3(SCAN_THREADS), 0, ctx->stream, S.planes.p, S.valid.p,
+				hipLaunchKernelGGL(k_scan, dim3(S.n_tiles), dim3(SCAN_THREADS), 0, ctx->stream, S.planes.p, S.valid_d(),
 					S.d_blk_off.p, S.d_len.p, S.d_active.p, S.tile_seq.p, S.tile_pos0.p, ctx->d_cand_fwd, ctx->d_cand_rc,
 					ctx->d_cand_floor, ncand, sink);
 				HIP_TRY(hipGetLastError());
@@ -2049,7 +2059,7 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 						Tg.masks = ST2.masks + 2*(size_t)or0; Tg.floors = ST2.floors + or0; Tg.n_or = g_or; Tg.or_base = or0;
 						g_begin = ctx->s2_group_end[g];
 						if(Tg.n_seeds == 0) continue;
-						const size_t dyn = 2*(size_t)g_or*sizeof(uint4) + (((size_t)g_or + 15) & ~size_t(15)) + 4*(size_t)Tg.n_seeds + 2*(((size_t)Tg.n_seeds + 1) & ~size_t(1)) + 16;
+						const size_t dyn = 2*(size_t)g_or*sizeof(uint4) + (((size_t)g_or + 15) & ~size_t(15)) + 8*((size_t)Tg.n_seeds + 64) + 16;   // masks | floors | chain | head (each with 64 dummy slots)
 						IrrArgs2 IA; IA.scan = S.irr_scan.p; IA.irr = S.irr.p; IA.n_live = n_live;
 						IA.off_mask = ctx->s2_group_offmask[g];
 						IA.exhaustive = first_launch ? 1u : 0u;                             // words holding IUPAC slots meet every candidate once, in the first launch
@@ -2064,7 +2074,7 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 							Z.z0 = (uint4 *)fa->d_fr; Z.z1 = (uint4 *)fa->d_rf; Z.n0 = Z.n1 = (uint32_t)(lean_bits_bytes/16); Z.ctrl = d_counters;
 							cleared_bits = true;
 						}
-						hipLaunchKernelGGL(k_seed2, sgrid, sblock, dyn, ctx->stream, S.tb.p, S.valid.p, S.tile_desc.p, S.n_tiles, Tg, S.d_active.p, ctx->d_cand_fwd, ctx->d_cand_floor, ncand, IA, sink,
+						hipLaunchKernelGGL(k_seed2, sgrid, sblock, dyn, ctx->stream, S.tb_d(), S.valid_d(), S.tile_desc.p, S.n_tiles, Tg, S.d_active.p, ctx->d_cand_fwd, ctx->d_cand_floor, ncand, IA, sink,
 							ctx->s2_dbg, Z);
 						HIP_TRY(hipGetLastError());
 						first_launch = false;
@@ -2097,7 +2107,7 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 					const dim3 fgrid(sgrid.x + irr_wgs);
 					irr_fused = true;
 					if(getenv("PCRAMP_DEBUG")) fprintf(stderr, "[pcramp] k_seed: %d workgroups per CU x %u CUs\n", per_cu, ctx->n_cu);
-#define SEED_ARGS S.tb.p, S.planes.p, S.valid.p, S.d_blk_off.p, S.d_nblk_real.p, S.d_len.p, S.d_active.p, S.tile_seq.p, S.tile_pos0.p, \
+#define SEED_ARGS S.tb_d(), S.planes.p, S.valid_d(), S.d_blk_off.p, S.d_nblk_real.p, S.d_len.p, S.d_active.p, S.tile_seq.p, S.tile_pos0.p, \
 	S.tile_degen.p, S.n_tiles, ST, ctx->d_cand_fwd, ctx->d_cand_rc, ctx->d_cand_floor, ncand, IA, sgrid.x, sink
 					if(cand_lds) hipLaunchKernelGGL(k_seed<true>, fgrid, sblock, dyn, ctx->stream, SEED_ARGS);
 					else hipLaunchKernelGGL(k_seed<false>, fgrid, sblock, dyn, ctx->stream, SEED_ARGS);
