@@ -699,6 +699,7 @@ struct pcr_ctx {
 	std::vector<uint16_t> seed_count; std::vector<uint8_t> seed_fill, seed_own;   // host scratch of the seed-table builder
 	uint32_t epoch = 0;         // pass counter tagging best[] (see HitSink)
 	uint32_t debug_epoch = 0;   // PCRAMP_DEBUG_EPOCH: value the counter takes when best[] is first cleared
+	bool opt_pm_global = false;   // PCRAMP_OPT_PM=global: k_pair_moves_batch (partner walk through global memory) instead of k_pair_moves_lds (A/B)
 	uint32_t opt_dbg_wg_tasks = 0, opt_dbg_task_cap = 0;   // PCRAMP_DEBUG_OPT_TASKS=<per workgroup>,<global>: shrink k_pair_moves_batch's task lists so that their overflow branches run (tests)
 	uint64_t best_seen = 0;      // generation of best[] that has been cleared (the allocator may hand the same address back: never compare pointers)
 	// pinned staging for the small per-call host->device payload (candidates, tables, oligos): one async copy
@@ -855,6 +856,18 @@ int build_tile_desc(pcr_ctx *ctx, SeqSet &S)
 		S.tile_pos0.p, S.tile_degen.p, S.n_tiles, S.tile_desc.p);
 	HIP_TRY(hipGetLastError());
 	return PCR_OK;
+}
+
+void fill_oligo_planes(OligoDev &o, const Planes &m, float thr2)
+{
+	o.m = m;
+	const unsigned size = (unsigned)pcrhost::planes_size(o.m);
+	o.floor2 = (unsigned)((float)size*thr2);                                     // optimize.cpp:293
+	o.norm = (size > 0) ? (float)(1.0/size) : 0.0f;                              // optimize.cpp:221
+	o.start = pcrhost::planes_start(o.m);
+	o.stop = pcrhost::planes_stop(o.m);
+	o.p1 = (o.stop >= 1) ? pcrhost::planes_nibble(o.m, o.stop - 1) : 0;
+	o.p2 = (o.stop >= 0) ? pcrhost::planes_nibble(o.m, o.stop) : 0;
 }
 
 void fill_oligo(OligoDev &o, const uint64_t w[2], float thr2)
@@ -1265,6 +1278,7 @@ pcr_ctx *pcr_create(int device, void *hip_stream, const pcr_params *params)
 	{ hipDeviceProp_t prop; if(hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->n_cu = (uint32_t)prop.multiProcessorCount; }
 	if(const char *v = getenv("PCRAMP_TIMING")) ctx->timing = v[0] == '1';
 	if(const char *v = getenv("PCRAMP_DEBUG_EPOCH")) ctx->debug_epoch = (uint32_t)strtoul(v, nullptr, 0);   // test hook: start the pass counter near its wrap
+	if(const char *v = getenv("PCRAMP_OPT_PM")) ctx->opt_pm_global = v[0] == 'g';
 	if(const char *v = getenv("PCRAMP_DEBUG_OPT_TASKS")){ unsigned a = 0, b = 0; if(sscanf(v, "%u,%u", &a, &b) >= 1){ ctx->opt_dbg_wg_tasks = a; ctx->opt_dbg_task_cap = b; } }
 	if(const char *v = getenv("PCRAMP_SEED")) ctx->force_seed1 = v[0] == '1';
 	if(const char *v = getenv("PCRAMP_SEED_TABLES")) ctx->host_seed_tables = v[0] == 'h';
