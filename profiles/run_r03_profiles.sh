@@ -2,9 +2,9 @@
 # Profiles of the default bench command (run on the GPU box from the repo root; results land under gpurun_out/).
 # rocprofv3 gets the interpreter itself after `--`; PMC passes run separately from the trace pass and from each other
 # (FETCH_SIZE and WRITE_SIZE do not fit one pass; MI355X_MICROARCH.md, rocprofv3 PMC slots).  Usage:
-#   bash profiles/run_r03_profiles.sh [tag] [passes]     passes: any of "stats fetch write sq sqb" (default: all)
+#   bash profiles/run_r03_profiles.sh [tag] [passes]     passes: any of "stats fetch write sq sqb sec secsq" (default: all)
 TAG=${1:-r03}
-PASSES=${2:-"stats fetch write sq sqb"}
+PASSES=${2:-"stats fetch write sq sqb sec secsq"}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 B="bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-secondary"
 for p in $PASSES; do
@@ -19,6 +19,11 @@ sq)    rocprofv3 --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_
 sqb)   # where the wave cycles go: issuing (ACTIVE_INST_*), stalled at issue (WAIT_INST_*), parked on s_waitcnt / barriers (WAIT_ANY)
        rocprofv3 --output-format csv --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM -d gpurun_out/${TAG}_sqb -- python3 $B > gpurun_out/${TAG}_sqb.log 2>&1
        python3 profiles/summarize.py sq gpurun_out/${TAG}_wave_cycles_pmc.json gpurun_out/${TAG}_sqb > gpurun_out/${TAG}_wave_cycles_pmc.md ;;
+sec)   # the secondary kernels (SW, thermodynamics, C3's background path, pcr_optimize_batch)
+       rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_sec -- python3 profiles/dbg/secondary_prof.py > gpurun_out/${TAG}_sec.log 2>&1
+       python3 profiles/summarize.py stats gpurun_out/${TAG}_sec > gpurun_out/${TAG}_kernel_stats_secondary.md ;;
+secsq) rocprofv3 --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAVES SQ_WAIT_INST_ANY -d gpurun_out/${TAG}_secsq -- python3 profiles/dbg/secondary_prof.py sw thermo c3bg > gpurun_out/${TAG}_secsq.log 2>&1
+       python3 profiles/summarize.py sq gpurun_out/${TAG}_secondary_pmc.json gpurun_out/${TAG}_secsq > gpurun_out/${TAG}_secondary_pmc.md ;;
 esac
 done
 exit 0
