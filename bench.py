@@ -34,7 +34,7 @@ HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_
 VALU_CLOCK_GHZ = 2.4        # MI355X engine clock (same guide); 256 CUs x 4 SIMDs, a wave64 VALU op holds its SIMD 4 clocks
 N_SIMD = 1024
 STRONG = {"C4": ("C4_shard", 8), "C5": ("C5_shard", 8)}       # name -> (block config, blocks of the fixed global set)
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
 
 
 # ---------------------------------------------------------------------------------------------- CPU baseline
@@ -265,7 +265,23 @@ def secondary_figures(api, synth, W, dev, stream, wl_single, scr0, pa, thr):
             kms, kn = s.profile_read_kernel(1)              # all launches of the three calls (a call is cut into chunks)
             s.profile(0)
             cells = sum(sum(1 for v in W.slots_from_word(a) if v) for a in q) / 2000.0 * 32
-            out["smith_waterman"] = {"lanes": n, "cells_per_lane": cells, "abi_GCUPS": n * cells / dt / 1e9,
+            qlens = [sum(1 for v in W.slots_from_word(a) if v) for a in q]
+            # lane utilisation of the anti-diagonal sweep: |q| x |t| cells in (|q| + |t| - 1) steps of 32 lanes
+            util = float(np.mean([ql * 32.0 / (32.0 * (ql + 32 - 1)) for ql in qlens]))
+            sec_pmc = load_profile_json("%s_secondary_pmc.json" % PROFILE_ROUND) or {}
+            sw_roof = {"bound": "valu", "lane_utilisation": util,
+                       "note": "k_sw_words carries start coordinates with every cell (five packed shuffles per anti-diagonal step); a |q| x 32 matrix keeps "
+                               "|q| x 32 / (32 x (|q| + 31)) of its lane-steps busy"}
+            hitk = [v for k, v in sec_pmc.items() if k == "k_sw_words" or k.startswith("k_sw_words")]
+            if hitk and hitk[0].get("SQ_INSTS_VALU") and kms > 0:
+                # the counter pass profiled the same 200 000-lane call (profiles/dbg/secondary_prof.py): instructions per launch = per chunk of 65 536 lanes
+                insts = hitk[0]["SQ_INSTS_VALU"]
+                k_s = (kms / max(kn, 1)) / 1e3
+                sw_roof.update({"valu_wave_instructions_per_launch": insts, "valu_issue_time_us": insts * 4.0 / (N_SIMD * VALU_CLOCK_GHZ * 1e9) * 1e6,
+                                "frac": insts * 4.0 / (N_SIMD * VALU_CLOCK_GHZ * 1e9) / k_s if k_s > 0 else None,
+                                "source": "profiles/%s_secondary_pmc.json (static)" % PROFILE_ROUND,
+                                "model": "SQ_INSTS_VALU x 4 clk / (1024 SIMDs x 2.4 GHz) / mean kernel time per launch"})
+            out["smith_waterman"] = {"lanes": n, "cells_per_lane": cells, "abi_GCUPS": n * cells / dt / 1e9, "roofline": sw_roof,
                                      "kernel_GCUPS": n * cells / (kms / reps / 1e3) / 1e9 if kms > 0 else None,
                                      "abi_ms_per_call": dt * 1e3, "kernel_ms_per_call": kms / reps, "kernel_launches_per_call": kn / reps,
                                      "note": "ABI: host words in, host results out, per call; kernel: HIP events around its launches"}
@@ -291,7 +307,19 @@ def secondary_figures(api, synth, W, dev, stream, wl_single, scr0, pa, thr):
             dt = (time.perf_counter() - t0) / reps
             kms, kn = s.profile_read_kernel(2)
             s.profile(0)
-            out["thermodynamics"] = {"oligos": m, "abi_oligos_per_s": m / dt, "abi_ms_per_call": dt * 1e3, "abi_ms_first_call": dt_first * 1e3,
+            th_roof = {"bound": "valu", "note": "one job per wave (is_valid = duplex Tm + hairpin + homodimer = 2 wave jobs per oligo): the DP fill runs the wave "
+                                                "along anti-diagonals, the trace-backs 8 lanes wide"}
+            sec_pmc = load_profile_json("%s_secondary_pmc.json" % PROFILE_ROUND) or {}
+            hitk = [v for k, v in sec_pmc.items() if "k_thermo_wave" in k]
+            if hitk and hitk[0].get("SQ_INSTS_VALU") and kms > 0:
+                insts = hitk[0]["SQ_INSTS_VALU"]
+                k_s = (kms / max(kn, 1)) / 1e3
+                th_roof.update({"valu_wave_instructions_per_launch": insts, "valu_issue_time_us": insts * 4.0 / (N_SIMD * VALU_CLOCK_GHZ * 1e9) * 1e6,
+                                "frac": insts * 4.0 / (N_SIMD * VALU_CLOCK_GHZ * 1e9) / k_s if k_s > 0 else None,
+                                "wave_cycles_parked_on_waitcnt": (hitk[0].get("SQ_WAIT_ANY") / hitk[0]["SQ_WAVE_CYCLES"]) if hitk[0].get("SQ_WAVE_CYCLES") else None,
+                                "source": "profiles/%s_secondary_pmc.json (static)" % PROFILE_ROUND,
+                                "model": "SQ_INSTS_VALU x 4 clk / (1024 SIMDs x 2.4 GHz) / kernel time"})
+            out["thermodynamics"] = {"oligos": m, "abi_oligos_per_s": m / dt, "abi_ms_per_call": dt * 1e3, "abi_ms_first_call": dt_first * 1e3, "roofline": th_roof,
                                      "kernel_ms": kms / reps, "kernel_launches": int(kn) // reps,
                                      "note": "is_valid with the homodimer test; mean of %d calls after one call of the same size (which allocates the buffers)" % reps}
         except Exception as e:                                         # noqa: BLE001
@@ -682,6 +710,20 @@ def main():
                         "lds_bank_conflict_cycles_per_launch": hit[0].get("SQ_LDS_BANK_CONFLICT"),
                         "source": "profiles/%s_valu_pmc%s.json (static: rocprofv3 --pmc pass of this command, committed)" % (PROFILE_ROUND, suffix),
                         "model": "SQ_INSTS_VALU x 4 clk / (1024 SIMDs x 2.4 GHz) / kernel time"}
+        # where the wave cycles of the scan kernel go, from the committed counter pass (SQ_WAVE_CYCLES = ACTIVE_INST_ANY + WAIT_INST_ANY
+        # + WAIT_ANY, quad-cycles summed over waves): issuing, stalled at issue (pipe busy), parked on s_waitcnt / barriers
+        wj = load_profile_json("%s_wave_cycles_pmc%s.json" % (PROFILE_ROUND, suffix)) if comparable else None
+        if wj and valu is not None:
+            hit = [v for k, v in wj.items() if is_kernel(k)]
+            if hit and hit[0].get("SQ_WAVE_CYCLES"):
+                h = hit[0]
+                wc = h["SQ_WAVE_CYCLES"]
+                valu["wave_cycles"] = {k2: (h.get(k1) / wc if h.get(k1) is not None else None) for k1, k2 in (
+                    ("SQ_ACTIVE_INST_ANY", "issuing"), ("SQ_ACTIVE_INST_VALU", "issuing_valu"), ("SQ_ACTIVE_INST_LDS", "issuing_lds"),
+                    ("SQ_WAIT_INST_ANY", "stalled_at_issue"), ("SQ_WAIT_INST_LDS", "stalled_at_issue_lds"), ("SQ_WAIT_ANY", "parked_on_waitcnt"))}
+                valu["wave_cycles"]["source"] = "profiles/%s_wave_cycles_pmc%s.json (static)" % (PROFILE_ROUND, suffix)
+                valu["wave_cycles"]["note"] = ("fractions of SQ_WAVE_CYCLES; 4 waves per SIMD, so issuing_valu x 4 = the share of the SIMD's time a VALU "
+                                               "instruction of one of its waves is in flight (one quad-cycle per wave64 instruction)")
         hbm_frac = achieved / HBM_PEAK_GBPS
         traffic_frac = (traffic / kern_s / 1e9 / HBM_PEAK_GBPS) if (traffic and kern_s > 0) else None
         bound = "valu" if (valu and valu["frac"] is not None and valu["frac"] > max(hbm_frac, traffic_frac or 0.0)) else "hbm"
