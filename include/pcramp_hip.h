@@ -426,6 +426,15 @@ typedef struct {
 int pcr_optimize_batch(pcr_ctx *ctx, const pcr_pair *assays, uint32_t n, const pcr_optimize_args *args, const pcr_pair *pool, uint32_t n_pool,
 	pcr_pair *best_out, float *score_out, uint32_t *iterations_out);
 
+/* make_degenerate (optimize.cpp:356-398 -> PCR::maximize_degeneracy, pcr_assay.cpp:111-230) for n trial assays: the top-down start of
+ * the local search (--optimize.top-down; main.cpp:709-721 calls it before optimize() and drops the trial when it returns false).
+ * The target word DB must have been built for these assays (pcr_select_words).  Reads of args: max_degen (opt.degen), thermo (salt,
+ * primer_strand, Tm range, max_hairpin, max_dimer: PCR::is_valid with the homodimer test, PCR::max_dimer_tm), target (collect
+ * threshold, amplicon range, use_taq_mama).  assays[i] is replaced by the maximally degenerate assay; valid[i] = what the reference
+ * returns (0: the greedy reduction ended non-degenerate with a heterodimer still above max_dimer).  Ties in the reference's
+ * std::sort of the candidate amplicons by score are resolved by the same libstdc++ algorithm on the same initial order. */
+int pcr_make_degenerate(pcr_ctx *ctx, pcr_pair *assays, uint32_t n, const pcr_optimize_args *args, uint8_t *valid);
+
 /* optimization_move (optimize.cpp:303-352): ONE move (PCR_MOVE_*) of ONE oligo (side 0 = F, 1 = R) of one assay.
  * score_threshold (3 floats, optional): the Score trials are measured against; NULL = the unmodified assay's own Score,
  * as optimization_move computes it.  word_out = the winning trial word (not re-centred; all zero if no trial survives),

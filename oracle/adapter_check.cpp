@@ -172,6 +172,26 @@ struct DeviceScreen {       // one per process (one GPU); not thread-safe, like 
 		return out;
 	}
 
+	// main.cpp:709-721 (--optimize.top-down): make_degenerate of every trial assay before optimize(); ok[t] = its return value
+	// (the reference drops the trial when it is false)
+	std::vector<bool> make_degenerate(std::vector<PCR> &trial, const Options &opt)
+	{
+		pcr_optimize_args o;
+		memset(&o, 0, sizeof(o));
+		o.max_degen = opt.degen; o.primer_min = opt.primer_range.first; o.primer_max = opt.primer_range.second;
+		o.thermo = thermo_args(opt);
+		const pcr_amplify_args ta = { opt.target_threshold*opt.target_search_multiplier, opt.target_threshold,
+			opt.target_amplicon_range.first, opt.target_amplicon_range.second, opt.use_taq_mama ? 1 : 0 };
+		o.target = ta;
+		std::vector<pcr_pair> p(trial.size());
+		for(size_t i = 0;i < trial.size();++i) p[i] = P(trial[i]);
+		std::vector<uint8_t> ok(trial.size() + 1);
+		check(pcr_make_degenerate(ctx, p.data(), (uint32_t)p.size(), &o, ok.data()));
+		std::vector<bool> out(trial.size());
+		for(size_t i = 0;i < trial.size();++i){ trial[i].oligo(FORWARD, W(p[i].f)); trial[i].oligo(REVERSE, W(p[i].r)); out[i] = ok[i] != 0; }
+		return out;
+	}
+
 	// main.cpp:744-803 for every trial assay: compatible[t] (:748-752) and the two background terms (:767-771, :786-803); the
 	// loop over t then only applies `best_score < s` and `s.background_coverage <= opt.max_background_cover`
 	void multiplex_screen(const std::vector<PCR> &trial, const std::deque<PCR> &pool, const Options &opt,
@@ -232,6 +252,7 @@ extern "C" int adapter_check_touch(int run)
 	const std::vector<Score> sc = d.optimize_trials(trial, std::deque<PCR>(), moves, false, opt);
 	std::vector<bool> comp; std::vector<float> mc, pc;
 	d.multiplex_screen(trial, std::deque<PCR>(), opt, comp, mc, pc);
+	if(d.make_degenerate(trial, opt).size() != trial.size()) return -1;
 	if(sc.size() != comp.size()) return -1;
 	return (int)c + (int)ok.size() + (int)d.assay_text(trial[0], std::deque<PCR>()).size();
 }

@@ -2,7 +2,8 @@
 // with real reference objects.  One process holds
 //   * deque<Sequence> / vector<PCR> / Options built with the reference's own constructors and setters,
 //   * the reference's functions for the design iteration's steps (Sequence::pack + select_words + MULTIMAP::sort + keys,
-//     PCR::find_target_match, collect/update/compute_target_coverage, PCR::find_background_match, PCR::is_valid, optimize())
+//     PCR::find_target_match, collect/update/compute_target_coverage, PCR::find_background_match, PCR::is_valid, make_degenerate(),
+//     optimize())
 //     -- main.cpp:579-691, 898, 824; optimize.cpp:14-207; valid_pcr.cpp:5 --
 //   * and DeviceScreen forwarding the same objects to libpcramp_hip.so,
 // and compares what comes back object for object: word-DB size, BitSet element by element, float coverage by value,
@@ -235,6 +236,20 @@ extern "C" int adapter_run(unsigned seed, unsigned n_families, unsigned per_fami
 			for(std::deque<int>::const_iterator m = moves.begin();m != moves.end();++m) ml.push_back(mv[*m]);
 			std::vector<PCR> dev_trial = trial;
 			const std::deque<PCR> pool;
+			{   // main.cpp:709-721: the top-down start, every trial assay at once against the reference's make_degenerate one by one
+				std::vector<PCR> deg = trial;
+				const std::vector<bool> ok = dev.make_degenerate(deg, oo);
+				for(unsigned t = 0;t < n_trials;++t){
+					PCR p = trial[t];
+					NucCruc melt; prefill(melt); melt.salt(oo.salt);
+					std::ostringstream sink;
+					const bool r_ok = make_degenerate(p, tkeys, tdb, target_seq, melt, oo, sink);
+					++st[0];
+					if(r_ok != ok[t] || !(p.oligo(FORWARD) == deg[t].oligo(FORWARD)) || !(p.oligo(REVERSE) == deg[t].oligo(REVERSE))){
+						++bad; std::cerr << "adapter_run: make_degenerate of assay " << t << " differs\n";
+					}
+				}
+			}
 			const std::vector<Score> dsc = dev.optimize_trials(dev_trial, pool, moves, true, oo);
 			const std::vector<Word> no_keys; const MULTIMAP<Word, WordMatch> no_db; const std::deque<Sequence> no_seq;
 			for(unsigned t = 0;t < n_trials;++t){

@@ -251,6 +251,42 @@ def moves_golden(ref):
     return {"cases": cases}
 
 
+def degenerate_golden(ref):
+    """make_degenerate (optimize.cpp:356-398 -> PCR::maximize_degeneracy: the top-down start of the local search) run by the
+    reference itself: resulting assay and return value, incl. cases whose max_dimer is low enough for the greedy heterodimer
+    reduction to run (and once to fail)."""
+    from oracle_lib import make_degenerate, DEFAULT_MOVE_OPTIONS
+    cases = []
+    for ci, case in enumerate([dict(degen=16), dict(degen=64, target_threshold=0.9, tm_min=40.0, tm_max=80.0, max_hairpin=50.0),
+                               dict(degen=8, target_threshold=0.85, use_taq_mama=1, tm_min=40.0, tm_max=80.0),
+                               dict(degen=64, max_dimer=20.0, tm_min=-100.0, tm_max=200.0, max_hairpin=500.0),
+                               dict(degen=64, max_dimer=12.0, tm_min=-100.0, tm_max=200.0, max_hairpin=500.0, seed=9103)]):
+        case = dict(case)
+        sess = {k: case.pop(k) for k in ("target_threshold", "use_taq_mama") if k in case}
+        rng = random.Random(case.pop("seed", 9100 + len(case) + 7 * len(sess)))
+        max_dimer = case.pop("max_dimer", 40.0)
+        seqs = family_targets(rng, 3, 12, 500, div=0.08)
+        weights = [1.0 + 0.3 * (i % 4) for i in range(len(seqs))]
+        pairs_txt = []
+        while len(pairs_txt) < 14:
+            p = sample_pair(rng, rng.choice(seqs))
+            if p:
+                pairs_txt.append(p)
+        pairs = [(ref.centered_word(a), ref.centered_word(b)) for a, b in pairs_txt]
+        ts = ref.session(**sess)
+        for q, wt in zip(seqs, weights):
+            ts.add_target(q, wt)
+        ts.select(pairs)
+        out = []
+        for p in pairs:
+            got, ok = make_degenerate(ref, ts, p, max_dimer=max_dimer, **case)
+            out.append([hexw(got[0]) + hexw(got[1]), int(ok)])
+        mo = dict(DEFAULT_MOVE_OPTIONS); mo.update(case)
+        cases.append({"options": ts.opts, "move_options": mo, "max_dimer": max_dimer, "seqs": seqs, "weights": weights,
+                      "pairs": [hexw(a) + hexw(b) for a, b in pairs], "degenerate": out})
+    return {"cases": cases}
+
+
 def sampler_inputs(ci):
     """Targets of the sampler cases: families with an IUPAC stretch, an EOS split, an inactive record and, for
     case 3, records barely longer than the amplicon."""
@@ -576,7 +612,8 @@ def main():
                      ("thermo", thermo_golden), ("moves", moves_golden), ("sampler", sampler_golden),
                      ("overlap", overlap_golden), ("multiplex", multiplex_golden),
                      ("multiplex_optimize", multiplex_optimize_golden), ("amplicons", amplicons_golden),
-                     ("background", background_golden), ("multiplex_match", multiplex_match_golden), ("writers", writers_golden)):
+                     ("background", background_golden), ("multiplex_match", multiplex_match_golden), ("writers", writers_golden),
+                     ("degenerate", degenerate_golden)):
         if only and name not in only:
             continue
         with open(os.path.join(OUT, name + ".json"), "w") as f:

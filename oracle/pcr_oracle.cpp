@@ -892,6 +892,68 @@ static int optimize_impl(orc_session *t, orc_session *b, const Mx *mx, uint64_t 
 	catch(const char *e){ t->err = e; return -1; }
 }
 
+extern "C" float orc_max_dimer_tm(const uint64_t pair[4], float salt, float primer_strand);
+
+// make_degenerate (optimize.cpp:356-398) -> PCR::maximize_degeneracy (pcr_assay.cpp:111-230): the top-down start of the
+// local search.  Candidates and identities of the assay (collect_target_candidates + update_target_candidates), the
+// amplicons sorted by sqrtf(f identity x r identity) descending (std::sort with assay.h:166-195's comparator on the
+// reference's amplicon order: the same libstdc++ algorithm, so the same permutation of ties), then the two greedy phases.
+int orc_make_degenerate(orc_session *t, uint64_t pair_inout[4], const orc_move_options *mo, float max_dimer, int *valid_out)
+{
+	try{
+		W F = load_word(pair_inout), R = load_word(pair_inout + 2);
+		std::vector<Amplicon> amp;
+		std::map<uint32_t, float> fi, ri;
+		collect_candidates(amp, fi, ri, F, R, *t, t->opt.target_threshold*t->opt.search_multiplier, t->opt.amp_min, t->opt.amp_max);   // assay.h:401-408
+		update_identity(fi, F, t->keys, t->opt.use_taq_mama != 0);
+		update_identity(ri, R, t->keys, t->opt.use_taq_mama != 0);
+		std::sort(amp.begin(), amp.end(), [&](const Amplicon &l, const Amplicon &r){
+			return sqrtf(fi[l.f]*ri[l.r]) > sqrtf(fi[r.f]*ri[r.r]); });                   // assay.h:176-194
+		auto unite = [](const W &w, const W &key){                                    // Word::operator|, word.h:421-440
+			W r = w;
+			const int first = w.start(), last = w.stop();
+			for(int i = first;i <= last;++i){ const unsigned b = key.get(i); if(b) r.set(r.get(i) | b, i); }
+			return r;
+		};
+		auto valid = [&](const W &w){
+			return orc_is_valid(w.b, mo->salt, mo->primer_strand, mo->tm_min, mo->tm_max, mo->max_hairpin, max_dimer, 1) == 1;
+		};
+		for(const Amplicon &a : amp){                                                 // pcr_assay.cpp:113-130
+			const W lf = unite(F, t->keys[a.f]), lr = unite(R, t->keys[a.r]);
+			if(lf.degeneracy() <= (double)mo->degen && valid(lf)) F = lf;
+			if(lr.degeneracy() <= (double)mo->degen && valid(lr)) R = lr;
+		}
+		auto dimer = [&](const W &f, const W &r){ const uint64_t p[4] = {f.b[0], f.b[1], r.b[0], r.b[1]}; return orc_max_dimer_tm(p, mo->salt, mo->primer_strand); };
+		float min_tm = dimer(F, R);                                                   // :132-229
+		const int last_f = F.stop(), last_r = R.stop();
+		int ok = 1;
+		while(min_tm > max_dimer){
+			float curr = 1.0e6f; int best_o = -1; W best;
+			for(int side = 0;side < 2;++side){
+				W &w = side ? R : F;
+				for(int i = w.start();i <= (side ? last_r : last_f);++i){
+					const unsigned cur = w.get(i);
+					for(unsigned b = 1;b <= 8;b <<= 1){
+						const unsigned d = cur & ~b;
+						if(!d || d == cur) continue;
+						w.set(d, i);
+						const float tm = dimer(F, R);
+						if(tm < curr){ curr = tm; best_o = side; best = w; }
+						w.set(cur, i);
+					}
+				}
+			}
+			if(best_o < 0){ ok = 0; break; }
+			if(best_o == 0) F = best; else R = best;
+			min_tm = curr;
+		}
+		pair_inout[0] = F.b[0]; pair_inout[1] = F.b[1]; pair_inout[2] = R.b[0]; pair_inout[3] = R.b[1];
+		if(valid_out) *valid_out = ok;
+		return 0;
+	}
+	catch(const char *e){ t->err = e; return -1; }
+}
+
 int orc_optimize(orc_session *t, orc_session *b, uint64_t pair_inout[4], const int *moves, int n_moves,
 	const orc_move_options *mo, float out_score[3], int *iterations_out)
 {

@@ -107,6 +107,10 @@ int orc_optimization_move(orc_session *t, orc_session *b, const uint64_t pair[4]
 int orc_optimize(orc_session *t, orc_session *b, uint64_t pair_inout[4], const int *moves, int n_moves,
 	const orc_move_options *mo, float out_score[3], int *iterations_out);
 
+// make_degenerate (optimize.cpp:356-398, PCR::maximize_degeneracy pcr_assay.cpp:111-230): pair_inout becomes the maximally
+// degenerate assay; *valid_out = the reference's return value.  Reads degen, the thermodynamic limits (+ max_dimer).
+int orc_make_degenerate(orc_session *t, uint64_t pair_inout[4], const orc_move_options *mo, float max_dimer, int *valid_out);
+
 // PCR::collect_unique_amplicons (pcr_assay.cpp:756-813) over the session's word DB (orc_session_select first):
 // bounds_out = n x {sequence, begin, end} in the reference's discovery order (AmpliconBounds, first/last base
 // incl. primers); amp_codes_out = the unique amplicon stretches (non-primer part + padding, pcr_assay.cpp:489-497)

@@ -462,6 +462,35 @@ int ref_optimize(RefSession *t, RefSession *b, uint64_t pair_inout[4], const int
 	catch(...){ t->last_error = "unknown"; return -2; }
 }
 
+// make_degenerate itself (optimize.cpp:356-398), with one NucCruc as main.cpp:702-716 gives it.
+int ref_make_degenerate(RefSession *t, uint64_t pair_inout[4], const RefMoveOptions *mo, float max_dimer, int *valid_out)
+{
+	try{
+		Options opt = t->opt;
+		opt.degen = mo->degen;
+		opt.primer_range = make_pair(mo->primer_min, mo->primer_max);
+		opt.salt = mo->salt; opt.primer_strand = mo->primer_strand;
+		opt.primer_tm_range = make_pair(mo->tm_min, mo->tm_max);
+		opt.max_hairpin = mo->max_hairpin;
+		opt.max_dimer = max_dimer;
+		opt.output_filter = Options::SILENT;
+		PCR p;
+		p.oligo( FORWARD, word_from(pair_inout) );
+		p.oligo( REVERSE, word_from(pair_inout + 2) );
+		NucCruc melt;
+		prefill(melt);
+		melt.salt(opt.salt);
+		std::ostringstream sink;
+		const bool ok = make_degenerate(p, t->target_keys, t->target_db, t->target_seq, melt, opt, sink);
+		words_of(p.oligo(FORWARD), pair_inout);
+		words_of(p.oligo(REVERSE), pair_inout + 2);
+		if(valid_out) *valid_out = ok ? 1 : 0;
+		return 0;
+	}
+	catch(const char *e){ t->last_error = e; return -1; }
+	catch(...){ t->last_error = "unknown"; return -2; }
+}
+
 // One move with opt.use_multiplex: candidates / identity tables / Score of the base assay as optimize() builds
 // them (optimize.cpp:61-97), then the reference's own optimization_move().
 int ref_optimization_move_multiplex(RefSession *t, RefSession *b, RefSession *amplicons, const uint64_t *pool_words, unsigned n_pool,

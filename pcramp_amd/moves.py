@@ -77,6 +77,21 @@ def optimize_batch(scr, pairs, move_list=DEFAULT_MOVES, **opts):
     return out, [tuple(np.float32(x) for x in s) for s in score[:n]], [int(i) for i in iters[:n]]
 
 
+def make_degenerate(scr, pairs, max_dimer=40.0, **opts):
+    """make_degenerate (optimize.cpp:356-398 -> PCR::maximize_degeneracy, pcr_assay.cpp:111-230) for a batch of trial assays:
+    the top-down start of the local search (--optimize.top-down) -> ([assay], [valid])."""
+    a = _args(DEFAULT_MOVES, **opts)
+    a.thermo.max_dimer = float(max_dimer)
+    pa = W.pairs_array(list(pairs)).copy()
+    n = pa.shape[0]
+    ok = np.zeros(max(n, 1), np.uint8)
+    fn = scr.L.pcr_make_degenerate
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(OptimizeArgs), C.c_void_p]
+    scr._check(fn(scr.h, pa.ctypes.data, n, C.byref(a), ok.ctypes.data))
+    out = [((int(r[0]), int(r[1])), (int(r[2]), int(r[3]))) for r in pa[:n]]
+    return out, [bool(v) for v in ok[:n]]
+
+
 def optimize(scr, pair, move_list=DEFAULT_MOVES, **opts):
     """optimize() (optimize.cpp:14-207) for one assay -> (best pair, Score)."""
     best, score, _ = optimize_batch(scr, [pair], move_list, **opts)

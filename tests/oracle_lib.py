@@ -330,6 +330,22 @@ def optimize(lib, target_session, background_session, pair, moves=(0, 1, 2, 4, 3
     return ((int(flat[0]), int(flat[1])), (int(flat[2]), int(flat[3]))), tuple(float(x) for x in sc)
 
 
+def make_degenerate(lib, target_session, pair, max_dimer=40.0, **mo):
+    """make_degenerate (optimize.cpp:356-398 -> PCR::maximize_degeneracy) -> (assay, valid)."""
+    o = dict(DEFAULT_MOVE_OPTIONS)
+    o.update(mo)
+    opts = MoveOptions(**o)
+    a = pairs_array([pair]).copy()
+    ok = C.c_int(0)
+    fn = getattr(lib.lib, lib.prefix + "make_degenerate")
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(MoveOptions), C.c_float, C.POINTER(C.c_int)]
+    rc = fn(target_session.h, a.ctypes.data, C.byref(opts), float(max_dimer), C.byref(ok))
+    if rc != 0:
+        raise RuntimeError(target_session.f("session_error")(target_session.h))
+    flat = a.reshape(-1)
+    return ((int(flat[0]), int(flat[1])), (int(flat[2]), int(flat[3]))), bool(ok.value)
+
+
 def optimization_move_multiplex(lib, target_session, background_session, amplicon_session, pool, pair, move, side, **mo):
     """One local-search move with opt.use_multiplex -> ((w0, w1), (tc, bc, overlap), base (tc, bc, overlap))."""
     o = dict(DEFAULT_MOVE_OPTIONS)

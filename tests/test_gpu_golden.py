@@ -118,6 +118,47 @@ def test_moves_golden(ci):
         d.close()
 
 
+@pytest.mark.parametrize("ci", range(5))
+def test_make_degenerate_golden(ci, oracle):
+    """pcr_make_degenerate (the top-down start of the local search, --optimize.top-down) against tests/golden/degenerate.json --
+    the reference's own make_degenerate (optimize.cpp:356-398 -> PCR::maximize_degeneracy): the resulting assays and return
+    values of a batch of 14 assays in one call, incl. the greedy heterodimer reduction and its failure exit; and the same
+    batch against the oracle with the assays in another order (the batch shares its thermodynamics rounds)."""
+    from pcramp_amd import moves
+    from oracle_lib import make_degenerate as oracle_make_degenerate
+    with open(os.path.join(G, "degenerate.json")) as f:
+        c = json.load(f)["cases"][ci]
+    o, mo = c["options"], c["move_options"]
+    pairs = [((int(p[0], 16), int(p[1], 16)), (int(p[2], 16), int(p[3], 16))) for p in c["pairs"]]
+    want = [(((int(w[0], 16), int(w[1], 16)), (int(w[2], 16), int(w[3], 16))), bool(ok)) for w, ok in c["degenerate"]]
+    kw = dict(target_threshold=o["target_threshold"], search_multiplier=o["search_multiplier"], amp_min=o["amp_min"], amp_max=o["amp_max"],
+              use_taq_mama=bool(o["use_taq_mama"]), **mo)
+    d = api.Screener(0)
+    try:
+        d.load_texts(c["seqs"], c["weights"], which=api.TARGET)
+        thr = float(np.float32(o["target_threshold"]) * np.float32(o["search_multiplier"]))
+        d.select_words(pairs, thr, o["min_primer"], o["optimize_5"], o["optimize_3"], which=api.TARGET)
+        got, ok = moves.make_degenerate(d, pairs, max_dimer=c["max_dimer"], **kw)
+        for k in range(len(pairs)):
+            assert (got[k], ok[k]) == want[k], k
+        assert sum(g != p for g, p in zip(got, pairs)) >= 3
+        # one assay per call, and the batch reversed: the same answers
+        for k in (0, 5, len(pairs) - 1):
+            g1, o1 = moves.make_degenerate(d, [pairs[k]], max_dimer=c["max_dimer"], **kw)
+            assert (g1[0], o1[0]) == want[k]
+        gr, okr = moves.make_degenerate(d, pairs[::-1], max_dimer=c["max_dimer"], **kw)
+        assert list(zip(gr, okr)) == want[::-1]
+        # the oracle beside it (it is pinned to the reference by the same fixture and by test_oracle_vs_reference)
+        ts = oracle.session(**o)
+        for q, wt in zip(c["seqs"], c["weights"]):
+            ts.add_target(q, wt)
+        ts.select(pairs)
+        for k in (1, 7):
+            assert oracle_make_degenerate(oracle, ts, pairs[k], max_dimer=c["max_dimer"], **mo) == want[k]
+    finally:
+        d.close()
+
+
 @pytest.mark.parametrize("ci", range(4))
 def test_sampler_golden(ci):
     """pcr_random_assays against tests/golden/sampler.json (the reference's PCR::random_assay on a running

@@ -116,6 +116,26 @@ def test_moves(oracle, ci):
         assert got[1] == tuple(float(np.float32(x)) for x in sc)
 
 
+@pytest.mark.parametrize("ci", range(5))
+def test_make_degenerate(oracle, ci):
+    """make_degenerate (optimize.cpp:356-398 -> PCR::maximize_degeneracy): the reference's resulting assay and return value
+    for 14 assays per case (tests/golden/degenerate.json), incl. the greedy heterodimer reduction and its failure exit."""
+    from oracle_lib import make_degenerate
+    c = load("degenerate")["cases"][ci]
+    ts = oracle.session(**c["options"])
+    for q, wt in zip(c["seqs"], c["weights"]):
+        ts.add_target(q, wt)
+    pairs = [((int(p[0], 16), int(p[1], 16)), (int(p[2], 16), int(p[3], 16))) for p in c["pairs"]]
+    ts.select(pairs)
+    changed = 0
+    for p, (wh, ok) in zip(pairs, c["degenerate"]):
+        got = make_degenerate(oracle, ts, p, max_dimer=c["max_dimer"], **c["move_options"])
+        assert got[0] == ((int(wh[0], 16), int(wh[1], 16)), (int(wh[2], 16), int(wh[3], 16)))
+        assert got[1] == bool(ok)
+        changed += got[0] != p
+    assert changed >= 3
+
+
 def _sampler_session(lib, c):
     sess = lib.session()
     for q, a in zip(c["seqs"], c["active"]):

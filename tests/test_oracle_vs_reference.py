@@ -639,3 +639,39 @@ def test_collect_unique_amplicons(oracle, reference, opts):
         assert ao == ar
         n_b += len(bo); n_a += len(ao)
     assert n_b >= 5 and n_a >= 3, (n_b, n_a)
+
+
+@pytest.mark.parametrize("case", [dict(degen=16), dict(degen=64, target_threshold=0.9, tm_min=40.0, tm_max=80.0, max_hairpin=50.0),
+                                  dict(degen=8, target_threshold=0.85, use_taq_mama=1, tm_min=40.0, tm_max=80.0),
+                                  dict(degen=64, max_dimer=20.0, tm_min=-100.0, tm_max=200.0, max_hairpin=500.0),
+                                  dict(degen=64, max_dimer=12.0, tm_min=-100.0, tm_max=200.0, max_hairpin=500.0, seed=9103)])
+def test_make_degenerate(oracle, reference, case):
+    """The reference's make_degenerate (optimize.cpp:356-398 -> PCR::maximize_degeneracy, pcr_assay.cpp:111-230: the top-down
+    start of the local search) against the oracle's restatement: resulting assay and return value.  Families 8 % apart so
+    that the unions with the matched keys add bases; the last two cases set max_dimer low enough for the greedy heterodimer
+    reduction (and its failure exit) to run."""
+    from oracle_lib import make_degenerate
+    case = dict(case)
+    sess = {k: case.pop(k) for k in ("target_threshold", "use_taq_mama") if k in case}
+    rng = random.Random(case.pop("seed", 9100 + len(case) + 7 * len(sess)))
+    seqs = family_targets(rng, 3, 12, 500, div=0.08)
+    pairs_txt = []
+    while len(pairs_txt) < 14:
+        p = sample_pair(rng, rng.choice(seqs))
+        if p:
+            pairs_txt.append(p)
+    pairs = [(reference.centered_word(f), reference.centered_word(r)) for f, r in pairs_txt]
+    to, tr = _sessions(oracle, reference, seqs, [1.0 + 0.3 * (i % 4) for i in range(len(seqs))], **sess)
+    assert to.select(pairs) == tr.select(pairs)
+    changed = reduced = 0
+    for p in pairs:
+        ro = make_degenerate(oracle, to, p, **case)
+        rr = make_degenerate(reference, tr, p, **case)
+        assert ro == rr, (p, ro, rr)
+        changed += ro[0] != p
+        if "max_dimer" in case:                     # did the heterodimer reduction change the outcome?
+            loose = dict(case, max_dimer=40.0)
+            reduced += make_degenerate(oracle, to, p, **loose) != ro
+    assert changed >= 3
+    if "max_dimer" in case:
+        assert reduced >= 1
