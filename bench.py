@@ -279,8 +279,11 @@ def secondary_figures(api, synth, W, dev, stream, wl_single, scr0, pa, thr):
                 k_s = (kms / max(kn, 1)) / 1e3
                 sw_roof.update({"valu_wave_instructions_per_launch": insts, "valu_issue_time_us": insts * 4.0 / (N_SIMD * VALU_CLOCK_GHZ * 1e9) * 1e6,
                                 "frac": insts * 4.0 / (N_SIMD * VALU_CLOCK_GHZ * 1e9) / k_s if k_s > 0 else None,
+                                "frac_at_2clk": insts * 2.0 / (N_SIMD * VALU_CLOCK_GHZ * 1e9) / k_s if k_s > 0 else None,
                                 "source": "profiles/%s_secondary_pmc.json (static)" % PROFILE_ROUND,
-                                "model": "SQ_INSTS_VALU x 4 clk / (1024 SIMDs x 2.4 GHz) / mean kernel time per launch"})
+                                "model": "SQ_INSTS_VALU x 4 clk (one wave's issue rate; x 2 clk = the SIMD-32's: frac_at_2clk) / (1024 SIMDs x 2.4 GHz) / mean "
+                                         "kernel time per launch; a value above 1 at 4 clk means the SIMDs overlap their waves' instructions, i.e. the kernel "
+                                         "is issue-bound"})
             out["smith_waterman"] = {"lanes": n, "cells_per_lane": cells, "abi_GCUPS": n * cells / dt / 1e9, "roofline": sw_roof,
                                      "kernel_GCUPS": n * cells / (kms / reps / 1e3) / 1e9 if kms > 0 else None,
                                      "abi_ms_per_call": dt * 1e3, "kernel_ms_per_call": kms / reps, "kernel_launches_per_call": kn / reps,
@@ -316,6 +319,7 @@ def secondary_figures(api, synth, W, dev, stream, wl_single, scr0, pa, thr):
                 k_s = (kms / max(kn, 1)) / 1e3
                 th_roof.update({"valu_wave_instructions_per_launch": insts, "valu_issue_time_us": insts * 4.0 / (N_SIMD * VALU_CLOCK_GHZ * 1e9) * 1e6,
                                 "frac": insts * 4.0 / (N_SIMD * VALU_CLOCK_GHZ * 1e9) / k_s if k_s > 0 else None,
+                                "frac_at_2clk": insts * 2.0 / (N_SIMD * VALU_CLOCK_GHZ * 1e9) / k_s if k_s > 0 else None,
                                 "wave_cycles_parked_on_waitcnt": (hitk[0].get("SQ_WAIT_ANY") / hitk[0]["SQ_WAVE_CYCLES"]) if hitk[0].get("SQ_WAVE_CYCLES") else None,
                                 "source": "profiles/%s_secondary_pmc.json (static)" % PROFILE_ROUND,
                                 "model": "SQ_INSTS_VALU x 4 clk / (1024 SIMDs x 2.4 GHz) / kernel time"})
@@ -706,10 +710,13 @@ def main():
                 busy_s = insts * 4.0 / (N_SIMD * VALU_CLOCK_GHZ * 1e9)
                 valu = {"wave_instructions_per_launch": insts, "issue_time_us": busy_s * 1e6,
                         "frac": (busy_s / kern_s) if kern_s > 0 else None,
+                        "frac_at_2clk": (busy_s / 2 / kern_s) if kern_s > 0 else None,
                         "lds_instructions_per_launch": hit[0].get("SQ_INSTS_LDS"),
                         "lds_bank_conflict_cycles_per_launch": hit[0].get("SQ_LDS_BANK_CONFLICT"),
                         "source": "profiles/%s_valu_pmc%s.json (static: rocprofv3 --pmc pass of this command, committed)" % (PROFILE_ROUND, suffix),
-                        "model": "SQ_INSTS_VALU x 4 clk / (1024 SIMDs x 2.4 GHz) / kernel time"}
+                        "model": "SQ_INSTS_VALU x 4 clk / (1024 SIMDs x 2.4 GHz) / kernel time: 4 clk is what ONE wave's stream sustains per instruction "
+                                 "(MI355X_MICROARCH.md, vector-instruction issue cost); a SIMD-32 with several ready waves retires a wave64 instruction in 2 "
+                                 "(frac_at_2clk), so the truth lies between; wave_cycles (counters) says where the waves' time goes"}
         # where the wave cycles of the scan kernel go, from the committed counter pass (SQ_WAVE_CYCLES = ACTIVE_INST_ANY + WAIT_INST_ANY
         # + WAIT_ANY, quad-cycles summed over waves): issuing, stalled at issue (pipe busy), parked on s_waitcnt / barriers
         wj = load_profile_json("%s_wave_cycles_pmc%s.json" % (PROFILE_ROUND, suffix)) if comparable else None
