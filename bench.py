@@ -346,9 +346,32 @@ def secondary_figures(api, synth, W, dev, stream, wl_single, scr0, pa, thr):
             for _ in range(reps):
                 s.find_background_match(p3, 0.8, 0.9, 0, 2000, False)
             t2 = time.perf_counter()
+            # the scan launch of that select_words (k_scan2 at k = 7: 0.72 has no seedable structure), HIP events on the launch stream
+            s.profile(1)
+            s.profile_read()
+            for _ in range(reps):
+                s.select_words(p3, bthr, 16, which=api.BACKGROUND, count=False)
+            kms, kn = s.profile_read()
+            s.profile(0)
+            k_s = kms / max(kn, 1) / 1e3
+            bg_bytes = float(np.asarray(bg["packed"]).nbytes) + 2 * len(c3["pairs"]) * 16
+            bg_roof = {"bound": "valu", "kernel": "k_scan2<7,..> (bit-sliced oligo x window scan of the background set at 0.8 x 0.9)",
+                       "kernel_ms": kms / max(kn, 1), "launches": int(kn), "algorithmic_bytes_per_launch": bg_bytes,
+                       "hbm_achieved_GBps": bg_bytes / k_s / 1e9 if k_s > 0 else None, "hbm_frac": bg_bytes / k_s / 1e9 / HBM_PEAK_GBPS if k_s > 0 else None,
+                       "note": "every window of every background against all 200 orientations in bit planes: the packed backgrounds are read once "
+                               "(HBM fraction tiny), the time is VALU instructions"}
+            sec_pmc = load_profile_json("%s_secondary_pmc.json" % PROFILE_ROUND) or {}
+            hitk = [v for k, v in sec_pmc.items() if k.startswith("k_scan2<7")]
+            if hitk and hitk[0].get("SQ_INSTS_VALU") and k_s > 0:
+                insts = hitk[0]["SQ_INSTS_VALU"]
+                bg_roof.update({"valu_wave_instructions_per_launch": insts, "valu_issue_time_us": insts * 4.0 / (N_SIMD * VALU_CLOCK_GHZ * 1e9) * 1e6,
+                                "frac": insts * 4.0 / (N_SIMD * VALU_CLOCK_GHZ * 1e9) / k_s, "frac_at_2clk": insts * 2.0 / (N_SIMD * VALU_CLOCK_GHZ * 1e9) / k_s,
+                                "wave_cycles_parked_on_waitcnt": (hitk[0].get("SQ_WAIT_ANY") / hitk[0]["SQ_WAVE_CYCLES"]) if hitk[0].get("SQ_WAVE_CYCLES") else None,
+                                "source": "profiles/%s_secondary_pmc.json (static)" % PROFILE_ROUND,
+                                "model": "SQ_INSTS_VALU x 4 clk / (1024 SIMDs x 2.4 GHz) / kernel time"})
             out["c3_background"] = {"backgrounds": int(bg["B"]), "pairs": len(c3["pairs"]), "select_words_ms": (t1 - t0) / reps * 1e3,
                                     "find_background_match_ms": (t2 - t1) / reps * 1e3,
-                                    "background_evals_per_s": bg["B"] * len(c3["pairs"]) / ((t2 - t0) / reps)}
+                                    "background_evals_per_s": bg["B"] * len(c3["pairs"]) / ((t2 - t0) / reps), "roofline": bg_roof}
         except Exception as e:                                         # noqa: BLE001
             out["c3_background"] = {"error": str(e)}
         # ---- the optimize() local search on the C2 targets + 2 000 backgrounds: one assay per call, and the trial assays

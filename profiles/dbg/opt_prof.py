@@ -1,5 +1,7 @@
-import sys, time
-sys.path.insert(0, '/root/repo')
+"""pcr_optimize_batch under a profiler: opt_prof.py single | batch N | both N  (256 sampler assays on the C2 targets + 2 000 backgrounds is
+what bench.py's secondary.optimize_batch times).  profiles/run_r03_profiles.sh passes `opt` and `optsq` run it under rocprofv3."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from pcramp_amd import api, synth, moves, words as W
 wl = synth.workload("C2")
@@ -26,6 +28,7 @@ if mode in ("batch", "both"):
     trial, _, _ = s.random_assays(2024, n)
     s.select_words(trial, thr, 18, count=False)
     s.select_words(trial, bthr, 16, which=api.BACKGROUND, count=False)
+    moves.optimize_batch(s, trial, **kw)                 # first call sizes the buffers
     t0 = time.perf_counter()
     _, _, it = moves.optimize_batch(s, trial, **kw)
     dt = time.perf_counter() - t0
