@@ -689,6 +689,7 @@ struct pcr_ctx {
 	DevBuf<uint64_t> amp_keys; DevBuf<uint32_t> amp_pkeys, amp_pair_start; DevBuf<uint8_t> sort_tmp;   // reference-order sort of the candidate amplicons (order_amplicons)
 	DevBuf<thermo::Job> th_jobs; DevBuf<thermo::JobOut> th_out; DevBuf<int> th_dg; DevBuf<uint2> th_map; DevBuf<uint32_t> th_bad;
 	float th_dg_salt = -1.0f;   // salt the table in th_dg was built for
+	DevBuf<unsigned long long> th_dbg; bool th_attr_set = false;
 	uint8_t *sw_pin = nullptr, *sw_pin_dev = nullptr; hipEvent_t sw_done[2] = {nullptr, nullptr};   // pcr_sw_align_words: two pinned chunk buffers (words in, results out)
 	DevBuf<pcr_amplicon> mx_amp;   // pcr_collect_amplicons records
 	DevBuf<OligoDev> opt_oligos; DevBuf<uint2> opt_jobs; DevBuf<float> opt_cov; DevBuf<uint32_t> opt_loc, opt_tasks;   // pcr_optimize_batch: base oligos + trial words, per-oligo variant ranges, coverages
@@ -1361,7 +1362,7 @@ void pcr_destroy(pcr_ctx *ctx)
 	if(ctx->ret_flag) (void)hipHostFree(ctx->ret_flag);
 	if(ctx->sw_pin) (void)hipHostFree(ctx->sw_pin);
 	for(int k = 0;k < 2;++k){ if(ctx->sw_done[k]) (void)hipEventDestroy(ctx->sw_done[k]); }
-	ctx->oligos.release(); ctx->sw_jobs.release(); ctx->sw_out.release(); ctx->sw_q.release(); ctx->sw_qlen.release(); ctx->sw_t.release(); ctx->entry_codes.release(); ctx->entry_lens.release(); ctx->amp_recs.release(); ctx->amp_recs2.release(); ctx->amp_keys.release(); ctx->amp_pkeys.release(); ctx->amp_pair_start.release(); ctx->sort_tmp.release(); ctx->bg_pairs.release(); ctx->th_jobs.release(); ctx->th_out.release(); ctx->th_dg.release(); ctx->th_map.release(); ctx->th_bad.release(); ctx->mx_keys.release(); ctx->mx_count.release(); ctx->mx_amp.release(); ctx->opt_oligos.release(); ctx->opt_jobs.release(); ctx->opt_cov.release(); ctx->opt_loc.release(); ctx->opt_tasks.release();
+	ctx->oligos.release(); ctx->sw_jobs.release(); ctx->sw_out.release(); ctx->sw_q.release(); ctx->sw_qlen.release(); ctx->sw_t.release(); ctx->entry_codes.release(); ctx->entry_lens.release(); ctx->amp_recs.release(); ctx->amp_recs2.release(); ctx->amp_keys.release(); ctx->amp_pkeys.release(); ctx->amp_pair_start.release(); ctx->sort_tmp.release(); ctx->bg_pairs.release(); ctx->th_jobs.release(); ctx->th_out.release(); ctx->th_dg.release(); ctx->th_dbg.release(); ctx->th_map.release(); ctx->th_bad.release(); ctx->mx_keys.release(); ctx->mx_count.release(); ctx->mx_amp.release(); ctx->opt_oligos.release(); ctx->opt_jobs.release(); ctx->opt_cov.release(); ctx->opt_loc.release(); ctx->opt_tasks.release();
 	if(ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
