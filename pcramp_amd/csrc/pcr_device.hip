@@ -661,6 +661,7 @@ struct pcr_ctx {
 	int device = 0;
 	hipStream_t stream = nullptr;
 	bool own_stream = false;
+	hipStream_t aux_stream = nullptr;   // the optimiser's thermodynamics run here, beside the coverage passes on `stream` (pcr_optimize.inc); created on first use
 	pcr_params params;
 	pcrhost::PackFilter filt;
 	SeqSet sets[PCR_N_SETS];   // target, background, multiplex (accepted amplicons), scratch (pcr_multiplex_screen's trial amplicons)
@@ -1363,6 +1364,7 @@ void pcr_destroy(pcr_ctx *ctx)
 	if(ctx->sw_pin) (void)hipHostFree(ctx->sw_pin);
 	for(int k = 0;k < 2;++k){ if(ctx->sw_done[k]) (void)hipEventDestroy(ctx->sw_done[k]); }
 	ctx->oligos.release(); ctx->sw_jobs.release(); ctx->sw_out.release(); ctx->sw_q.release(); ctx->sw_qlen.release(); ctx->sw_t.release(); ctx->entry_codes.release(); ctx->entry_lens.release(); ctx->amp_recs.release(); ctx->amp_recs2.release(); ctx->amp_keys.release(); ctx->amp_pkeys.release(); ctx->amp_pair_start.release(); ctx->sort_tmp.release(); ctx->bg_pairs.release(); ctx->th_jobs.release(); ctx->th_out.release(); ctx->th_dg.release(); ctx->th_dbg.release(); ctx->th_map.release(); ctx->th_bad.release(); ctx->mx_keys.release(); ctx->mx_count.release(); ctx->mx_amp.release(); ctx->opt_oligos.release(); ctx->opt_jobs.release(); ctx->opt_cov.release(); ctx->opt_loc.release(); ctx->opt_tasks.release();
+	if(ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
 	if(ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
