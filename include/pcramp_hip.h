@@ -496,6 +496,38 @@ int64_t pcr_format_assay(const pcr_output *o, const pcr_assay_record *rec, const
 int64_t pcr_format_footer(const pcr_output *o, const uint8_t *target_active, const uint64_t *total_background,
 	char *out, uint64_t cap);
 
+/* ---- The design loop over all of the above (scope row f-7): what `pcramp` does between reading its FASTA files and closing
+ * its output file (main.cpp:131-163, 440-443, 471-1264), one rank, one thread. */
+
+/* The `Options` fields that loop reads (pcramp.h:83-128; the pack filters are pcr_create's, sequences, weights and deflines
+ * are the loaded sets' and pcr_output's). */
+typedef struct {
+	uint32_t num_assay;              /* --count: stop after this many design iterations */
+	uint32_t num_trial;              /* --trial: trial assays per iteration (of this rank, main.cpp:66) */
+	uint32_t seed;                   /* --seed: global_seed (main.cpp:113); one rand_r draw per iteration feeds the sampler */
+	int32_t  top_down_search;        /* --optimize.top-down: make_degenerate before optimize() */
+	int32_t  optimize_5, optimize_3; /* shifted candidates in select_words, the trim / grow moves */
+	float    target_threshold, target_search_multiplier;
+	float    background_threshold, background_search_multiplier;
+	float    min_target_cover, max_background_cover;
+	int32_t  target_amp_min, target_amp_max, background_amp_min, background_amp_max;
+	int32_t  primer_min, primer_max; /* opt.primer_range; primer_min is also Options::min_oligo_length() */
+	double   max_degen;              /* -d: > 1 enables the degeneracy moves (main.cpp:82-86) */
+	pcr_thermo_args thermo;
+	int32_t  use_taq_mama, use_multiplex;
+} pcr_design_args;
+
+/* Runs the design loop on the loaded PCR_SET_TARGET / PCR_SET_BACKGROUND sets (weights, active flags and EOS splits as they
+ * stand; the call changes them exactly as the reference changes its target_seq: detected targets become inactive, accepted
+ * amplicons split their targets) and leaves the bytes of the reference's output file in the handle (pcr_design_output).
+ * argc / argv: the command line the header quotes.  pool_out (optional, pool_cap entries): the accepted assays in order;
+ * n_pool_out: their number.  Where the reference throws (e.g. the sampler finds no valid assay) the error code and its text
+ * are returned and the output so far stays readable. */
+int pcr_design(pcr_ctx *ctx, const pcr_design_args *args, const pcr_output *o, int argc, const char *const *argv,
+	pcr_pair *pool_out, uint32_t pool_cap, uint32_t *n_pool_out);
+/* The text of the last pcr_design call (valid until the next one or pcr_destroy). */
+const char *pcr_design_output(pcr_ctx *ctx, uint64_t *len_out);
+
 /* ---- Host-only helpers (pure CPU arithmetic of the host half of the index build; usable
  * without a GPU; exercised by the `not gpu` tests). */
 

@@ -603,6 +603,52 @@ def writers_golden(ref):
     return {"oligos": oligos, "runs": runs}
 
 
+def program_golden(ref):
+    """Scope row f-7: more whole runs of the reference PROGRAM (as writers_golden's, oracle/_ref/pcramp, one rank, one thread) with the
+    switches those do not use: the top-down start, the 5' / 3' moves, TaqMAMA, a relaxed background gate on close backgrounds.
+    tests/test_gpu_design_program.py replays the command lines through pcr_design."""
+    import subprocess
+    import tempfile
+    from testdata import mutate
+    exe = os.path.join(ROOT, "oracle", "_ref", "pcramp")
+    specs = [dict(n_fam=2, per=4, L=520, n_bg=2, div=0.04, bg_div=0.12, args=["--count", "4", "--trial", "30", "--seed", "11", "-d", "8", "--optimize.top-down"]),
+             dict(n_fam=2, per=4, L=520, n_bg=2, div=0.04, bg_div=0.12, args=["--count", "4", "--trial", "30", "--seed", "11", "-d", "8", "--optimize.top-down", "--o.json"]),
+             dict(n_fam=2, per=3, L=480, n_bg=2, div=0.05, bg_div=0.10, args=["--count", "4", "--trial", "25", "--seed", "5", "-d", "4", "--optimize.5", "--optimize.3",
+                                                                             "--target.threshold", "0.9"]),
+             dict(n_fam=3, per=3, L=450, n_bg=3, div=0.03, bg_div=0.04, args=["--count", "5", "--trial", "30", "--seed", "23", "--background.cover", "2",
+                                                                             "--background.threshold", "0.75"]),
+             dict(n_fam=2, per=3, L=450, n_bg=1, div=0.05, bg_div=0.08, args=["--count", "3", "--trial", "25", "--seed", "3", "-d", "2", "--primer.taq-mama",
+                                                                             "--target.threshold", "0.85", "--optimize.3"]),
+             dict(n_fam=1, per=5, L=700, n_bg=0, div=0.02, bg_div=0.0, args=["--count", "9", "--trial", "20", "--seed", "77"])]
+    runs = []
+    with tempfile.TemporaryDirectory() as tmp:
+        libdir = os.path.join(tmp, "lib")
+        os.makedirs(libdir)
+        for so in ("libmpi.so.12", "libgfortran.so.4", "libquadmath.so.0"):
+            os.symlink(os.path.join("/opt/conda/lib", so), os.path.join(libdir, so))
+        env = dict(os.environ, LD_LIBRARY_PATH=libdir, OMP_NUM_THREADS="1")
+        for si, sp in enumerate(specs):
+            input_seed = 7100 + si // 2
+            r2 = random.Random(input_seed)
+            roots = [rand_seq(r2, sp["L"] + 7 * k) for k in range(sp["n_fam"])]
+            targets = [(">target_%d family %d" % (k * sp["per"] + j, k), mutate(r2, roots[k], sp["div"])) for k in range(sp["n_fam"]) for j in range(sp["per"])]
+            bgs = [(">bg_%d" % i, mutate(r2, roots[i % len(roots)], sp["bg_div"])) for i in range(sp["n_bg"])]
+            with open(os.path.join(tmp, "t.fa"), "w") as f:
+                f.write("".join("%s\n%s\n" % (d, q) for d, q in targets))
+            argv = ["pcramp", "-t", "t.fa", "-o", "out.txt", "--thread", "1"] + sp["args"]
+            if bgs:
+                with open(os.path.join(tmp, "b.fa"), "w") as f:
+                    f.write("".join("%s\n%s\n" % (d, q) for d, q in bgs))
+                argv += ["-b", "b.fa"]
+            subprocess.check_call([exe] + argv[1:], cwd=tmp, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            out = open(os.path.join(tmp, "out.txt"), "rb").read().decode("latin-1").replace(exe, "pcramp")
+            runs.append({"argv": argv, "seed": int(sp["args"][sp["args"].index("--seed") + 1]), "json": int("--o.json" in sp["args"]),
+                         "input_seed": input_seed, "spec": {k: sp[k] for k in ("n_fam", "per", "L", "n_bg", "div", "bg_div")},
+                         "targets": [[d, len(q)] for d, q in targets], "backgrounds": [[d, len(q)] for d, q in bgs], "output": out})
+            print("program run", si, argv[7:], "->", out.count("ASSAY.") + out.count('"forward primer"'), "assays,", out.count("\nB-"), "background lines")
+    return {"runs": runs}
+
+
 def main():
     build_reference()
     ref = Reference()
@@ -613,7 +659,7 @@ def main():
                      ("overlap", overlap_golden), ("multiplex", multiplex_golden),
                      ("multiplex_optimize", multiplex_optimize_golden), ("amplicons", amplicons_golden),
                      ("background", background_golden), ("multiplex_match", multiplex_match_golden), ("writers", writers_golden),
-                     ("degenerate", degenerate_golden)):
+                     ("degenerate", degenerate_golden), ("program", program_golden)):
         if only and name not in only:
             continue
         with open(os.path.join(OUT, name + ".json"), "w") as f:

@@ -117,6 +117,7 @@ ABI_SYMBOLS = [
     "pcr_multiplex_load", "pcr_multiplex_coverage", "pcr_collect_amplicons",
     "pcr_format_oligos", "pcr_format_header", "pcr_format_iteration", "pcr_format_assay", "pcr_format_footer",
     "pcr_optimize_batch", "pcr_optimization_move", "pcr_make_degenerate", "pcr_staging_mode",
+    "pcr_design", "pcr_design_output",
     "pcr_comm_unique_id", "pcr_comm_init_rank", "pcr_comm_world", "pcr_comm_rank", "pcr_exchange_bits", "pcr_comm_destroy", "pcr_comm_library",
 ]
 

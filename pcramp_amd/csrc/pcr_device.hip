@@ -661,6 +661,7 @@ struct pcr_ctx {
 	int device = 0;
 	hipStream_t stream = nullptr;
 	bool own_stream = false;
+	std::string design_text;            // the output file of the last pcr_design call
 	hipStream_t aux_stream = nullptr;   // the optimiser's thermodynamics run here, beside the coverage passes on `stream` (pcr_optimize.inc); created on first use
 	pcr_params params;
 	pcrhost::PackFilter filt;
