@@ -374,6 +374,29 @@ def secondary_figures(api, synth, W, dev, stream, wl_single, scr0, pa, thr):
                                     "background_evals_per_s": bg["B"] * len(c3["pairs"]) / ((t2 - t0) / reps), "roofline": bg_roof}
         except Exception as e:                                         # noqa: BLE001
             out["c3_background"] = {"error": str(e)}
+        # ---- the reference PROGRAM's design loop (pcr_design = main.cpp:471-1130 behind the ABI) on the C2 targets with the reference's
+        # default options (1 000 trial assays per iteration, -d 1, multiplex on), three iterations, no backgrounds
+        try:
+            from pcramp_amd import design
+            wl = wl_single
+            dz = api.Screener(dev, stream=stream)                      # a handle of its own: the call changes active flags and splits targets
+            try:
+                dz.load_sequences(wl["packed"], wl["byte_offsets"], wl["lengths"], which=api.TARGET)
+                T = int(wl["T"])
+                defl = [">t%d" % i for i in range(T)]
+                t0 = time.perf_counter()
+                text, pool = design.design(dz, defl, [int(x) for x in wl["lengths"]], argv=["pcramp", "--count", "3", "--seed", "42"],
+                                           num_assay=3, num_trial=1000, seed=42)
+                dt = time.perf_counter() - t0
+            finally:
+                dz.close()
+            out["design_loop"] = {"targets": T, "trial_assays_per_iteration": 1000, "iterations": 3, "assays_accepted": len(pool),
+                                  "ms_per_iteration": dt / 3 * 1e3, "output_bytes": len(text),
+                                  "evals_per_s": 3 * 1000 * T / dt,
+                                  "note": "whole design iterations: sampler, select_words for 1 000 assays, optimize(), multiplex filter, "
+                                          "find_target_match, amplicon DB, EOS splits, output text; evals = trial assays x targets per iteration"}
+        except Exception as e:                                         # noqa: BLE001
+            out["design_loop"] = {"error": str(e)}
         # ---- the optimize() local search on the C2 targets + 2 000 backgrounds: one assay per call, and the trial assays
         # of a design iteration as ONE batch (pcr_optimize_batch; main.cpp:697-887 runs optimize() for num_trial assays)
         try:

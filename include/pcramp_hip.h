@@ -90,6 +90,9 @@ int pcr_set_active(pcr_ctx *ctx, pcr_set which, const uint8_t *active);
 
 /* Sequence::split_sequence (sequence.h:228-241; main.cpp:1008-1017): write EOS at `pos`. */
 int pcr_split(pcr_ctx *ctx, pcr_set which, uint32_t seq, uint64_t pos);
+/* n splits at once (the three per amplicon of an accepted assay, main.cpp:1008-1017: a few hundred per design iteration): the
+ * derived device state -- window validity around each split, the set's irregular word list -- is refreshed once. */
+int pcr_split_many(pcr_ctx *ctx, pcr_set which, const uint32_t *seq, const uint64_t *pos, uint32_t n);
 
 /* The per-iteration index build, main.cpp:579-615 / 644-691: for every ACTIVE sequence
  * Sequence::pack (sequence.cpp:92) + select_words (select_words.cpp:8) with the trial assays

@@ -662,6 +662,7 @@ struct pcr_ctx {
 	hipStream_t stream = nullptr;
 	bool own_stream = false;
 	std::string design_text;            // the output file of the last pcr_design call
+	DevBuf<uint64_t> split_where;       // pcr_split_many's (block, bit) list
 	hipStream_t aux_stream = nullptr;   // the optimiser's thermodynamics run here, beside the coverage passes on `stream` (pcr_optimize.inc); created on first use
 	pcr_params params;
 	pcrhost::PackFilter filt;
@@ -790,39 +791,65 @@ struct HostTimer {
 	~HostTimer() { next(slot); }
 };
 
+// pcr_split_many: where[2i] = block of the plane store, where[2i+1] = bit of the base in it.  Several splits may share a block.
+__global__ void k_apply_splits(const uint64_t *__restrict__ where, uint32_t n, uint32_t *__restrict__ planes /* uint4 per block */, uint32_t *__restrict__ nib)
+{
+	const uint32_t i = blockIdx.x*blockDim.x + threadIdx.x;
+	if(i >= n) return;
+	const uint64_t gb = where[2*(size_t)i];
+	const uint32_t bit = (uint32_t)where[2*(size_t)i + 1];
+	const uint32_t m = ~(1u << bit);
+	for(int k = 0;k < 4;++k) atomicAnd(&planes[gb*4 + k], m);
+	atomicAnd(&nib[gb*4 + (bit >> 3)], ~(0xFu << ((bit & 7u)*4u)));
+}
+
 int upload_irregular(pcr_ctx *ctx, SeqSet &S)
 {
-	std::vector<IrrDev> flat;
+	size_t total = 0;
+	for(uint32_t s = 0;s < S.n;++s) total += S.irr_host[s].size();
+	std::vector<IrrDev> flat(total);
 	std::vector<uint32_t> off(S.n + 1, 0);
-	for(uint32_t s = 0;s < S.n;++s){
-		off[s] = (uint32_t)flat.size();
-		for(size_t k = 0;k < S.irr_host[s].size();++k){
-			const pcrhost::IrrEntry &e = S.irr_host[s][k];
-			IrrDev d;
-			d.w = e.w; d.loc = e.loc; d.seq = s;
-			d.meta = (uint32_t)e.strand | ((uint32_t)e.cws << 8) | ((uint32_t)e.ord << 16);
-			d.local_id = (uint32_t)k;
-			flat.push_back(d);
+	for(int k = 0;k < 256;++k) S.irr_size_count[k] = 0;
+	{
+		size_t at = 0;
+		for(uint32_t s = 0;s < S.n;++s){
+			off[s] = (uint32_t)at;
+			const std::vector<pcrhost::IrrEntry> &v = S.irr_host[s];
+			for(size_t k = 0;k < v.size();++k){
+				const pcrhost::IrrEntry &e = v[k];
+				IrrDev &d = flat[at++];
+				d.w = e.w; d.loc = e.loc; d.seq = s;
+				d.meta = (uint32_t)e.strand | ((uint32_t)e.cws << 8) | ((uint32_t)e.ord << 16);
+				d.local_id = (uint32_t)k;
+				++S.irr_size_count[e.cws & 0xFF];
+			}
 		}
 	}
 	off[S.n] = (uint32_t)flat.size();
 	S.n_irr = (uint32_t)flat.size();
-	// scan order: by size counter, largest first, so that a pass with min_oligo_length m walks a prefix
-	// (sequence.cpp:157,239 drop the words whose counter is below m)
+	// scan order: by size counter, largest first, so that a pass with min_oligo_length m walks a prefix (sequence.cpp:157,239 drop
+	// the words whose counter is below m); equal counters keep the list's order.  A counting sort: the list is rebuilt after every
+	// accepted assay of a design run (pcr_split_many), and a comparison sort of C2's 3e5 words was most of the 280 ms that took.
 	std::vector<uint32_t> perm(flat.size());
-	for(size_t i = 0;i < perm.size();++i) perm[i] = (uint32_t)i;
-	std::stable_sort(perm.begin(), perm.end(), [&flat](uint32_t a, uint32_t b){ return ((flat[a].meta >> 8) & 0xFF) > ((flat[b].meta >> 8) & 0xFF); });
-	for(int k = 0;k < 256;++k) S.irr_size_count[k] = 0;
-	for(const IrrDev &d : flat) ++S.irr_size_count[(d.meta >> 8) & 0xFF];
+	{
+		uint32_t start[256];
+		uint32_t run = 0;
+		for(int k = 255;k >= 0;--k){ start[k] = run; run += S.irr_size_count[k]; }
+		for(size_t i = 0;i < flat.size();++i) perm[start[(flat[i].meta >> 8) & 0xFF]++] = (uint32_t)i;
+	}
 	int rc;
 	{
+		// bits of a 32-bit plane to the even positions of a 64-bit word
+		auto spread = [](uint64_t v) -> uint64_t {
+			v = (v | (v << 16)) & 0x0000FFFF0000FFFFull; v = (v | (v << 8)) & 0x00FF00FF00FF00FFull; v = (v | (v << 4)) & 0x0F0F0F0F0F0F0F0Full;
+			v = (v | (v << 2)) & 0x3333333333333333ull; v = (v | (v << 1)) & 0x5555555555555555ull; return v;
+		};
 		std::vector<IrrScan> scan(perm.size());
 		for(size_t i = 0;i < perm.size();++i){
 			const IrrDev &d = flat[perm[i]];
 			const uint32_t multi = (d.w.a & d.w.c) | (d.w.a & d.w.g) | (d.w.a & d.w.t) | (d.w.c & d.w.g) | (d.w.c & d.w.t) | (d.w.g & d.w.t);
 			const uint32_t lo = d.w.c | d.w.t, hi = d.w.g | d.w.t;             // 2-bit code planes (A,C,G,T = 0..3; empty slots read as A)
-			uint64_t code = 0;
-			for(int k = 0;k < 32;++k) code |= ((uint64_t)(((lo >> k) & 1u) | (((hi >> k) & 1u) << 1))) << (2*k);
+			const uint64_t code = spread(lo) | (spread(hi) << 1);
 			IrrScan r; r.w0 = (uint32_t)code; r.w1 = (uint32_t)(code >> 32); r.idx_flags = perm[i] | (multi ? 0x80000000u : 0u); r.seq = d.seq;
 			scan[i] = r;
 		}
@@ -1364,7 +1391,7 @@ void pcr_destroy(pcr_ctx *ctx)
 	if(ctx->ret_flag) (void)hipHostFree(ctx->ret_flag);
 	if(ctx->sw_pin) (void)hipHostFree(ctx->sw_pin);
 	for(int k = 0;k < 2;++k){ if(ctx->sw_done[k]) (void)hipEventDestroy(ctx->sw_done[k]); }
-	ctx->oligos.release(); ctx->sw_jobs.release(); ctx->sw_out.release(); ctx->sw_q.release(); ctx->sw_qlen.release(); ctx->sw_t.release(); ctx->entry_codes.release(); ctx->entry_lens.release(); ctx->amp_recs.release(); ctx->amp_recs2.release(); ctx->amp_keys.release(); ctx->amp_pkeys.release(); ctx->amp_pair_start.release(); ctx->sort_tmp.release(); ctx->bg_pairs.release(); ctx->th_jobs.release(); ctx->th_out.release(); ctx->th_dg.release(); ctx->th_dbg.release(); ctx->th_map.release(); ctx->th_bad.release(); ctx->mx_keys.release(); ctx->mx_count.release(); ctx->mx_amp.release(); ctx->opt_oligos.release(); ctx->opt_jobs.release(); ctx->opt_cov.release(); ctx->opt_loc.release(); ctx->opt_tasks.release();
+	ctx->oligos.release(); ctx->sw_jobs.release(); ctx->sw_out.release(); ctx->sw_q.release(); ctx->sw_qlen.release(); ctx->sw_t.release(); ctx->entry_codes.release(); ctx->entry_lens.release(); ctx->amp_recs.release(); ctx->amp_recs2.release(); ctx->amp_keys.release(); ctx->amp_pkeys.release(); ctx->amp_pair_start.release(); ctx->sort_tmp.release(); ctx->bg_pairs.release(); ctx->th_jobs.release(); ctx->th_out.release(); ctx->th_dg.release(); ctx->th_dbg.release(); ctx->split_where.release(); ctx->th_map.release(); ctx->th_bad.release(); ctx->mx_keys.release(); ctx->mx_count.release(); ctx->mx_amp.release(); ctx->opt_oligos.release(); ctx->opt_jobs.release(); ctx->opt_cov.release(); ctx->opt_loc.release(); ctx->opt_tasks.release();
 	if(ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
 	if(ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
@@ -1554,40 +1581,60 @@ int pcr_set_active(pcr_ctx *ctx, pcr_set which, const uint8_t *active)
 	return PCR_OK;
 }
 
-int pcr_split(pcr_ctx *ctx, pcr_set which, uint32_t seq, uint64_t pos)
+int pcr_split_many(pcr_ctx *ctx, pcr_set which, const uint32_t *seq, const uint64_t *pos, uint32_t n)
 {
 	if(!set_ok(which)){ g_err = "pcr_split: unknown sequence set"; return PCR_ERR_ARG; }
-	if(!ctx){ g_err = "null ctx"; return PCR_ERR_ARG; }
+	if(!ctx || (n && (!seq || !pos))){ g_err = "pcr_split: bad argument"; return PCR_ERR_ARG; }
+	if(n == 0) return PCR_OK;
 	DRAIN(ctx);
 	HIP_TRY(hipSetDevice(ctx->device));
-	HIP_TRY(hipStreamSynchronize(ctx->stream));        // the null-stream copies below must not overlap a pass still reading planes / has_eos
 	SeqSet &S = ctx->sets[which];
-	if(seq >= S.n || pos >= S.len[seq]){ g_err = "pcr_split: out of range"; return PCR_ERR_ARG; }
-	uint8_t &v = S.packed[seq][pos >> 1];
-	v = (pos & 1) ? (v & 0xF0) : (v & 0x0F);                                     // sequence.h:232-241
-	if(!S.has_eos[seq]){ S.has_eos[seq] = 1; HIP_TRY(hipMemcpy(S.d_has_eos.p + seq, &S.has_eos[seq], 1, hipMemcpyHostToDevice)); }
-	// device: clear the base in its block, refresh the 2 blocks of windows that can see it, redo the irregular list
-	const uint64_t gb = S.blk_off[seq] + (pos >> 5);
-	uint4 blk;
-	HIP_TRY(hipMemcpy(&blk, S.planes.p + gb, sizeof(uint4), hipMemcpyDeviceToHost));
-	const uint32_t m = ~(1u << (pos & 31));
-	blk.x &= m; blk.y &= m; blk.z &= m; blk.w &= m;
-	HIP_TRY(hipMemcpy(S.planes.p + gb, &blk, sizeof(uint4), hipMemcpyHostToDevice));
-	{
-		uint32_t nword;
-		uint32_t *np = S.nib.p + gb*4 + ((pos & 31) >> 3);
-		HIP_TRY(hipMemcpy(&nword, np, sizeof(uint32_t), hipMemcpyDeviceToHost));
-		nword &= ~(0xFu << ((pos & 7)*4));
-		HIP_TRY(hipMemcpy(np, &nword, sizeof(uint32_t), hipMemcpyHostToDevice));
+	for(uint32_t i = 0;i < n;++i){ if(seq[i] >= S.n || pos[i] >= S.len[seq[i]]){ g_err = "pcr_split: out of range"; return PCR_ERR_ARG; } }
+	// host copy, and what the device has to change: per split the block of the plane store and the base's bit in it
+	std::vector<uint64_t> where(2*(size_t)n);
+	std::vector<uint32_t> touched_seq;
+	bool eos_changed = false;
+	for(uint32_t i = 0;i < n;++i){
+		uint8_t &v = S.packed[seq[i]][pos[i] >> 1];
+		v = (pos[i] & 1) ? (v & 0xF0) : (v & 0x0F);                                // sequence.h:232-241
+		if(!S.has_eos[seq[i]]){ S.has_eos[seq[i]] = 1; eos_changed = true; }
+		where[2*(size_t)i] = S.blk_off[seq[i]] + (pos[i] >> 5); where[2*(size_t)i + 1] = pos[i] & 31u;
+		touched_seq.push_back(seq[i]);
 	}
-	const uint64_t first = (gb > S.blk_off[seq]) ? gb - 1 : gb;
-	int rc = run_valid(ctx, S, first, gb - first + 1);
-	if(rc != PCR_OK) return rc;
-	S.irr_host[seq].clear();
-	pcrhost::PackedSeq q; q.buf = S.packed[seq].data(); q.len = S.len[seq];
-	if(!pcrhost::irregular_words(q, ctx->filt, S.irr_host[seq])){ g_err = "pcr_split: irregular word overflow"; return PCR_ERR_CAPACITY; }
+	std::sort(touched_seq.begin(), touched_seq.end());
+	touched_seq.erase(std::unique(touched_seq.begin(), touched_seq.end()), touched_seq.end());
+	int rc;
+	if(eos_changed) HIP_TRY(hipMemcpyAsync(S.d_has_eos.p, S.has_eos.data(), S.n, hipMemcpyHostToDevice, ctx->stream));
+	// device: clear the bases in their blocks (one launch), refresh the 2 blocks of windows that can see each, redo the irregular
+	// lists of the sequences concerned and upload the set's list ONCE (it is rebuilt whole: sort by size counter, scan records --
+	// 20 ms for C2's 3e5 words, which a design iteration's ~600 splits each paid when this took one split per call)
+	if((rc = ctx->split_where.ensure(where.size())) != PCR_OK) return rc;
+	HIP_TRY(hipMemcpyAsync(ctx->split_where.p, where.data(), where.size()*sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+	hipLaunchKernelGGL(k_apply_splits, dim3((n + 255)/256), dim3(256), 0, ctx->stream, ctx->split_where.p, n, (uint32_t *)S.planes.p, S.nib.p);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(ctx->stream));                                   // `where` is a local
+	for(uint32_t i = 0;i < n;++i){
+		const uint64_t gb = where[2*(size_t)i];
+		const uint64_t first = (gb > S.blk_off[seq[i]]) ? gb - 1 : gb;
+		if((rc = run_valid(ctx, S, first, gb - first + 1)) != PCR_OK) return rc;
+	}
+	const auto t0 = std::chrono::steady_clock::now();
+	for(uint32_t sq : touched_seq){
+		S.irr_host[sq].clear();
+		pcrhost::PackedSeq q; q.buf = S.packed[sq].data(); q.len = S.len[sq];
+		if(!pcrhost::irregular_words(q, ctx->filt, S.irr_host[sq])){ g_err = "pcr_split: irregular word overflow"; return PCR_ERR_CAPACITY; }
+	}
 	S.have_db = false; S.have_codes = false;
-	return upload_irregular(ctx, S);
+	const auto t1 = std::chrono::steady_clock::now();
+	rc = upload_irregular(ctx, S);
+	if(ctx->timing) fprintf(stderr, "[pcramp] split_many: %u splits in %zu sequences; irregular words %.1f ms, list upload %.1f ms\n", n, touched_seq.size(),
+		std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
+	return rc;
+}
+
+int pcr_split(pcr_ctx *ctx, pcr_set which, uint32_t seq, uint64_t pos)
+{
+	return pcr_split_many(ctx, which, &seq, &pos, 1);
 }
 
 } // extern "C"
