@@ -1658,7 +1658,7 @@ bool plan_seed2(pcr_ctx *ctx, const std::vector<pcrhost::Candidate> &cand, std::
 	irr_off_mask = 0;
 	if(ctx->s2_cache.size() > 16384) ctx->s2_cache.clear();
 	size_t group_begin = 0; uint32_t group_mask = 0, group_or0 = 0, group_last = 0;
-	auto fits = [&](size_t n, uint32_t g_or){ return g_or <= S2_MAX_OR && n <= S2_MAX_SEEDS && sizeof(S2Shared) + 32*(size_t)g_or + 8*n + 1024 <= 160*1024; };   // the tables of a launch must fit one CU's LDS
+	auto fits = [&](size_t n, uint32_t g_or){ return g_or <= S2_MAX_OR && n <= S2_MAX_SEEDS && sizeof(S2Shared) + 17*(size_t)g_or + 8*n + 1024 <= 160*1024; };   // the tables of a launch must fit one CU's LDS
 	for(uint32_t o = 0;o < n_or;++o){
 		const pcrhost::Candidate &c = cand[o >> 1];
 		const Planes &m = (o & 1u) ? c.rc : c.fwd;
@@ -1980,12 +1980,14 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 		bytes += (H.image.size() + H.heads.size() + H.multi.size() + 64)*sizeof(uint32_t);
 		std::vector<uint4> &masks2 = ctx->s2_masks; std::vector<uint8_t> &floors2 = ctx->s2_floors;
 		if(use_seed2){
-			// per orientation: the four base-set planes spread to even bits (slot k -> bit 2k), slots 0..15 | 16..31
-			masks2.resize(2*(size_t)n_or); floors2.assign(((size_t)n_or + 15) & ~size_t(15), 0);
+			// per orientation ONE 16-byte entry: the four base-set planes, slots 0..15 spread to the even bits (slot k -> bit 2k) and
+			// slots 16..31 to the odd bits (slot 16 + k -> bit 2k + 1): both halves of a window are counted by one multiplexer pass
+			// (s2_count) from one LDS read
+			masks2.resize((size_t)n_or); floors2.assign(((size_t)n_or + 15) & ~size_t(15), 0);
 			for(uint32_t o = 0;o < n_or;++o){
 				const Planes &m = (o & 1u) ? cand[o >> 1].rc : cand[o >> 1].fwd;
-				masks2[2*o] = make_uint4(spread16(m.a), spread16(m.c), spread16(m.g), spread16(m.t));
-				masks2[2*o + 1] = make_uint4(spread16(m.a >> 16), spread16(m.c >> 16), spread16(m.g >> 16), spread16(m.t >> 16));
+				masks2[o] = make_uint4(spread16(m.a) | (spread16(m.a >> 16) << 1), spread16(m.c) | (spread16(m.c >> 16) << 1),
+				                       spread16(m.g) | (spread16(m.g >> 16) << 1), spread16(m.t) | (spread16(m.t >> 16) << 1));
 				floors2[o] = (uint8_t)std::min<uint32_t>(cand[o >> 1].floor_, 255u);
 			}
 			bytes += masks2.size()*sizeof(uint4) + floors2.size() + ctx->s2_seeds.size()*sizeof(uint32_t) + 512;
@@ -2112,7 +2114,8 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 					const dim3 sgrid(std::max<uint32_t>(1u, std::min<uint32_t>((S.n_tiles + tiles_per_wg - 1)/tiles_per_wg, ctx->n_cu))), sblock(S2_THREADS);
 					irr_fused = true;
 					if(!ctx->s2_attr_set){
-						HIP_TRY(hipFuncSetAttribute((const void *)k_seed2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160*1024 - sizeof(S2Shared))));
+						HIP_TRY(hipFuncSetAttribute((const void *)k_seed2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160*1024 - sizeof(S2Shared))));
+						HIP_TRY(hipFuncSetAttribute((const void *)k_seed2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160*1024 - sizeof(S2Shared))));
 						ctx->s2_attr_set = true;
 					}
 					uint32_t g_begin = 0;
@@ -2121,10 +2124,10 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 						Seed2Tables Tg = ST2;
 						const uint32_t or0 = ctx->s2_group_or[g], g_or = ctx->s2_group_nor[g];
 						Tg.seeds = ST2.seeds + g_begin; Tg.n_seeds = ctx->s2_group_end[g] - g_begin;
-						Tg.masks = ST2.masks + 2*(size_t)or0; Tg.floors = ST2.floors + or0; Tg.n_or = g_or; Tg.or_base = or0;
+						Tg.masks = ST2.masks + (size_t)or0; Tg.floors = ST2.floors + or0; Tg.n_or = g_or; Tg.or_base = or0;
 						g_begin = ctx->s2_group_end[g];
 						if(Tg.n_seeds == 0) continue;
-						const size_t dyn = 2*(size_t)g_or*sizeof(uint4) + (((size_t)g_or + 15) & ~size_t(15)) + 8*((size_t)Tg.n_seeds + 64) + 16;   // masks | floors | chain | head (each with 64 dummy slots)
+						const size_t dyn = (size_t)g_or*sizeof(uint4) + (((size_t)g_or + 15) & ~size_t(15)) + 8*((size_t)Tg.n_seeds + 64) + 16;   // masks | floors | chain | head (each with 64 dummy slots)
 						IrrArgs2 IA; IA.scan = S.irr_scan.p; IA.irr = S.irr.p; IA.n_live = n_live;
 						IA.off_mask = ctx->s2_group_offmask[g];
 						IA.exhaustive = first_launch ? 1u : 0u;                             // words holding IUPAC slots meet every candidate once, in the first launch
@@ -2139,7 +2142,11 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 							Z.z0 = (uint4 *)fa->d_fr; Z.z1 = (uint4 *)fa->d_rf; Z.n0 = Z.n1 = (uint32_t)(lean_bits_bytes/16); Z.ctrl = d_counters;
 							cleared_bits = true;
 						}
-						hipLaunchKernelGGL(k_seed2, sgrid, sblock, dyn, ctx->stream, S.tb_d(), S.valid_d(), S.tile_desc.p, S.n_tiles, Tg, S.d_active.p, ctx->d_cand_fwd, ctx->d_cand_floor, ncand, IA, sink,
+						if(ctx->s2_dbg)
+							hipLaunchKernelGGL(k_seed2<true>, sgrid, sblock, dyn, ctx->stream, S.tb_d(), S.valid_d(), S.tile_desc.p, S.n_tiles, Tg, S.d_active.p, ctx->d_cand_fwd, ctx->d_cand_floor, ncand, IA, sink,
+							ctx->s2_dbg, Z);
+						else
+							hipLaunchKernelGGL(k_seed2<false>, sgrid, sblock, dyn, ctx->stream, S.tb_d(), S.valid_d(), S.tile_desc.p, S.n_tiles, Tg, S.d_active.p, ctx->d_cand_fwd, ctx->d_cand_floor, ncand, IA, sink,
 							ctx->s2_dbg, Z);
 						HIP_TRY(hipGetLastError());
 						first_launch = false;
