@@ -228,6 +228,39 @@ struct DeviceScreen {       // one per process (one GPU); not thread-safe, like 
 		s.resize((size_t)n);
 		return s;
 	}
+
+	// main.cpp:131-163, 440-443, 471-1264 in one call: the design loop on the loaded sets and the bytes `fout` receives.  What stays in
+	// main() is Options::load, parse_fasta, load() of both sets and writing the returned text to opt.output_filename.
+	std::string design(const Options &opt, const std::deque<Sequence> &targets, const std::deque<Sequence> &backgrounds, int argc, char *argv[])
+	{
+		pcr_design_args a;
+		memset(&a, 0, sizeof(a));
+		a.num_assay = opt.num_assay; a.num_trial = opt.num_trial; a.seed = opt.seed; a.top_down_search = opt.top_down_search ? 1 : 0;
+		a.optimize_5 = opt.optimize_5 ? 1 : 0; a.optimize_3 = opt.optimize_3 ? 1 : 0;
+		a.target_threshold = opt.target_threshold; a.target_search_multiplier = opt.target_search_multiplier;
+		a.background_threshold = opt.background_threshold; a.background_search_multiplier = opt.background_search_multiplier;
+		a.min_target_cover = opt.min_target_cover; a.max_background_cover = opt.max_background_cover;
+		a.target_amp_min = opt.target_amplicon_range.first; a.target_amp_max = opt.target_amplicon_range.second;
+		a.background_amp_min = opt.background_amplicon_range.first; a.background_amp_max = opt.background_amplicon_range.second;
+		a.primer_min = opt.primer_range.first; a.primer_max = opt.primer_range.second; a.max_degen = opt.degen;
+		a.thermo = thermo_args(opt); a.use_taq_mama = opt.use_taq_mama ? 1 : 0; a.use_multiplex = opt.use_multiplex ? 1 : 0;
+		std::vector<std::string> td, bd;
+		std::vector<const char *> tp, bp;
+		std::vector<uint64_t> tl, bl;
+		for(std::deque<Sequence>::const_iterator i = targets.begin();i != targets.end();++i){ td.push_back(i->defline()); tl.push_back(i->length()); }
+		for(std::deque<Sequence>::const_iterator i = backgrounds.begin();i != backgrounds.end();++i){ bd.push_back(i->defline()); bl.push_back(i->length()); }
+		for(size_t i = 0;i < td.size();++i) tp.push_back(td[i].c_str());
+		for(size_t i = 0;i < bd.size();++i) bp.push_back(bd[i].c_str());
+		pcr_output o;
+		memset(&o, 0, sizeof(o));
+		o.json = (opt.output_format == Options::JSON_OUTPUT) ? 1 : 0; o.use_multiplex = opt.use_multiplex ? 1 : 0;
+		o.n_target = (uint32_t)td.size(); o.n_background = (uint32_t)bd.size();
+		o.target_deflines = tp.data(); o.background_deflines = bp.data(); o.target_lengths = tl.data(); o.background_lengths = bl.data();
+		check(pcr_design(ctx, &a, &o, argc, (const char *const *)argv, NULL, 0, NULL));
+		uint64_t n = 0;
+		const char *text = pcr_design_output(ctx, &n);
+		return std::string(text, (size_t)n);
+	}
 };
 
 // one function that instantiates every member, so that the whole adapter is compiled and linked, not only parsed
@@ -254,5 +287,7 @@ extern "C" int adapter_check_touch(int run)
 	d.multiplex_screen(trial, std::deque<PCR>(), opt, comp, mc, pc);
 	if(d.make_degenerate(trial, opt).size() != trial.size()) return -1;
 	if(sc.size() != comp.size()) return -1;
-	return (int)c + (int)ok.size() + (int)d.assay_text(trial[0], std::deque<PCR>()).size();
+	char *no_args[1] = { NULL };
+	const std::string file = d.design(opt, seq, std::deque<Sequence>(), 0, no_args);
+	return (int)c + (int)ok.size() + (int)d.assay_text(trial[0], std::deque<PCR>()).size() + (int)file.size();
 }
