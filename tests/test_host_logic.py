@@ -276,3 +276,18 @@ def test_host_overlap_helpers(oracle):
         a = c["assay"]
         pool = [((int(p[0], 16), int(p[1], 16)), (int(p[2], 16), int(p[3], 16))) for p in c["pool"]]
         assert api.host_oligo_overlap(((int(a[0], 16), int(a[1], 16)), (int(a[2], 16), int(a[3], 16))), pool) == np.float32(c["overlap"])
+
+
+def test_design_options_from_argv():
+    """pcramp_amd.design maps the reference's command-line switches (options.cpp:161-214) onto pcr_design_args; unknown ones raise."""
+    from pcramp_amd import design
+    o = design.options_from_argv(["pcramp", "-t", "t.fa", "-o", "out.txt", "--thread", "1", "--count", "3", "--trial", "40", "--seed", "42",
+                                  "-d", "8", "--optimize.top-down", "--optimize.3", "--target.threshold", "0.9", "--o.json", "-b", "b.fa"])
+    assert (o["num_assay"], o["num_trial"], o["seed"], o["max_degen"]) == (3, 40, 42, 8.0)
+    assert o["top_down_search"] == 1 and o["optimize_3"] == 1 and o["optimize_5"] == 0 and o["json"] == 1
+    assert o["target_threshold"] == 0.9 and o["background_threshold"] == design.DEFAULTS["background_threshold"]
+    assert design.DEFAULTS["use_multiplex"] == 1 and design.DEFAULTS["num_trial"] == 1000          # options.cpp:72, pcramp.h:32
+    with pytest.raises(ValueError):
+        design.options_from_argv(["pcramp", "--no-such-switch"])
+    import ctypes as C
+    assert C.sizeof(design.DesignArgs) == 112                                                      # pcr_design_args, include/pcramp_hip.h
