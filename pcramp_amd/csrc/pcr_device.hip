@@ -44,6 +44,10 @@
 #include <unordered_map>
 #include <type_traits>
 #include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <functional>
+#include <memory>
 
 #include "../../include/pcramp_hip.h"
 #include "pcr_host.hpp"
@@ -657,8 +661,45 @@ struct SeqSet {
 
 } // namespace
 
+// A few host threads that live as long as the handle (pcr_optimize.inc's loops over the assays of a batch).  run(): part indices
+// 0 .. n_parts-1 are claimed one by one by the workers and by the calling thread, which returns when all are done.
+struct HostPool {
+	std::vector<std::thread> th;
+	std::mutex m; std::condition_variable cv_go, cv_done;
+	std::function<void(unsigned)> fn; unsigned n_parts = 0, next = 0, pending = 0; uint64_t gen = 0; bool stop = false;
+	explicit HostPool(unsigned n_workers){ for(unsigned i = 0;i < n_workers;++i) th.emplace_back([this]{ work(); }); }
+	~HostPool(){ { std::lock_guard<std::mutex> lk(m); stop = true; } cv_go.notify_all(); for(std::thread &t : th) t.join(); }
+	unsigned size() const { return (unsigned)th.size(); }
+	void work()
+	{
+		uint64_t seen = 0;
+		std::unique_lock<std::mutex> lk(m);
+		while(true){
+			cv_go.wait(lk, [&]{ return stop || gen != seen; });
+			if(stop) return;
+			seen = gen;
+			while(next < n_parts){ const unsigned p = next++; lk.unlock(); fn(p); lk.lock(); }
+			if(--pending == 0) cv_done.notify_one();
+		}
+	}
+	void run(unsigned parts, std::function<void(unsigned)> f)
+	{
+		std::unique_lock<std::mutex> lk(m);
+		fn = std::move(f); n_parts = parts; next = 0; pending = (unsigned)th.size(); ++gen;
+		cv_go.notify_all();
+		while(next < n_parts){ const unsigned p = next++; lk.unlock(); fn(p); lk.lock(); }
+		cv_done.wait(lk, [&]{ return pending == 0; });
+	}
+};
+
 struct pcr_ctx {
 	int device = 0;
+	std::unique_ptr<HostPool> pool_;
+	HostPool &host_pool()
+	{
+		if(!pool_){ const unsigned hw = std::max(1u, std::thread::hardware_concurrency()); pool_.reset(new HostPool(std::min(hw, 16u) - 1u)); }   // (a GPU box gives its process 16 cores)
+		return *pool_;
+	}
 	hipStream_t stream = nullptr;
 	bool own_stream = false;
 	std::string design_text;            // the output file of the last pcr_design call
