@@ -619,7 +619,11 @@ def program_golden(ref):
                                                                              "--background.threshold", "0.75"]),
              dict(n_fam=2, per=3, L=450, n_bg=1, div=0.05, bg_div=0.08, args=["--count", "3", "--trial", "25", "--seed", "3", "-d", "2", "--primer.taq-mama",
                                                                              "--target.threshold", "0.85", "--optimize.3"]),
-             dict(n_fam=1, per=5, L=700, n_bg=0, div=0.02, bg_div=0.0, args=["--count", "9", "--trial", "20", "--seed", "77"])]
+             dict(n_fam=1, per=5, L=700, n_bg=0, div=0.02, bg_div=0.0, args=["--count", "9", "--trial", "20", "--seed", "77"]),
+             # backgrounds that ARE the targets' roots and a generous background gate (the reference still reports no cross-reaction: see
+             # tests/test_writers.py's note on the B- branches)
+             dict(n_fam=2, per=4, L=500, n_bg=2, div=0.03, bg_div=0.0, args=["--count", "4", "--trial", "30", "--seed", "19", "--background.cover", "4"]),
+             dict(n_fam=2, per=4, L=500, n_bg=2, div=0.03, bg_div=0.0, args=["--count", "4", "--trial", "30", "--seed", "19", "--background.cover", "4", "--o.json"])]
     runs = []
     with tempfile.TemporaryDirectory() as tmp:
         libdir = os.path.join(tmp, "lib")
