@@ -1259,11 +1259,11 @@ int amplify_launch(pcr_ctx *ctx, SeqSet &S, const pcr_pair *pairs, uint32_t n_pa
 }
 
 template<int NSLOT, int KLO>
-int launch_scan2_nw(pcr_ctx *ctx, SeqSet &S, uint32_t nw, uint32_t group0, uint32_t n_groups, uint32_t ncand, const HitSink &sink,
+int launch_scan2_nw(pcr_ctx *ctx, SeqSet &S, uint32_t nw, uint32_t group0, uint32_t n_groups, uint32_t gw, uint32_t ncand, const HitSink &sink,
 	const uint32_t *d_tab, const uint32_t *d_bias, const uint32_t *tile_ids, uint32_t n_tiles, const uint32_t *orient_ids)
 {
 #define SCAN2_ARGS S.nib.p, S.planes.p, S.valid_d(), S.d_blk_off.p, S.d_len.p, S.d_active.p, S.tile_seq.p, S.tile_pos0.p, \
-	d_tab, d_bias, group0, tile_ids, orient_ids, ctx->d_cand_fwd, ctx->d_cand_rc, ctx->d_cand_floor, ncand, sink
+	d_tab, d_bias, group0, gw, tile_ids, orient_ids, ctx->d_cand_fwd, ctx->d_cand_rc, ctx->d_cand_floor, ncand, sink
 	const dim3 grid(n_tiles, n_groups), block(SCAN2_THREADS);
 	switch(nw){
 		case 1: hipLaunchKernelGGL((k_scan2<1, NSLOT, KLO>), grid, block, 0, ctx->stream, SCAN2_ARGS); break;
@@ -1286,16 +1286,16 @@ int launch_scan2(pcr_ctx *ctx, SeqSet &S, const Scan2Tables &T, uint32_t ncand, 
 	const uint32_t *d_tab, const uint32_t *d_bias, const uint32_t *tile_ids, uint32_t n_tiles, const uint32_t *orient_ids)
 {
 	if(n_tiles == 0 || T.n_groups == 0) return PCR_OK;
-	const uint32_t full = (T.last_words == 8) ? T.n_groups : T.n_groups - 1;
+	const uint32_t full = (T.last_words == T.gw) ? T.n_groups : T.n_groups - 1;
 	int rc = PCR_OK;
 	if(full){
-		rc = (T.nslot == 26) ? launch_scan2_nw<26, 3>(ctx, S, 8, 0, full, ncand, sink, d_tab, d_bias, tile_ids, n_tiles, orient_ids)
-			: launch_scan2_nw<32, 0>(ctx, S, 8, 0, full, ncand, sink, d_tab, d_bias, tile_ids, n_tiles, orient_ids);
+		rc = (T.nslot == 26) ? launch_scan2_nw<26, 3>(ctx, S, T.gw, 0, full, T.gw, ncand, sink, d_tab, d_bias, tile_ids, n_tiles, orient_ids)
+			: launch_scan2_nw<32, 0>(ctx, S, T.gw, 0, full, T.gw, ncand, sink, d_tab, d_bias, tile_ids, n_tiles, orient_ids);
 		if(rc != PCR_OK) return rc;
 	}
 	if(full < T.n_groups){
-		rc = (T.nslot == 26) ? launch_scan2_nw<26, 3>(ctx, S, T.last_words, full, 1, ncand, sink, d_tab, d_bias, tile_ids, n_tiles, orient_ids)
-			: launch_scan2_nw<32, 0>(ctx, S, T.last_words, full, 1, ncand, sink, d_tab, d_bias, tile_ids, n_tiles, orient_ids);
+		rc = (T.nslot == 26) ? launch_scan2_nw<26, 3>(ctx, S, T.last_words, full, 1, T.gw, ncand, sink, d_tab, d_bias, tile_ids, n_tiles, orient_ids)
+			: launch_scan2_nw<32, 0>(ctx, S, T.last_words, full, 1, T.gw, ncand, sink, d_tab, d_bias, tile_ids, n_tiles, orient_ids);
 	}
 	return rc;
 }

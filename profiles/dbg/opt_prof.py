@@ -28,6 +28,11 @@ if mode in ("batch", "both"):
     trial, _, _ = s.random_assays(2024, n)
     s.select_words(trial, thr, 18, count=False)
     s.select_words(trial, bthr, 16, which=api.BACKGROUND, count=False)
+    s.synchronize()
+    t0 = time.perf_counter()
+    s.select_words(trial, bthr, 16, which=api.BACKGROUND, count=False)
+    s.synchronize()
+    print("background select_words for", n, "assays: %.2f ms" % ((time.perf_counter() - t0) * 1e3))
     moves.optimize_batch(s, trial, **kw)                 # first call sizes the buffers
     t0 = time.perf_counter()
     _, _, it = moves.optimize_batch(s, trial, **kw)
