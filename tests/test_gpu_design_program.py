@@ -60,12 +60,20 @@ def test_more_program_runs():
     path = os.path.join(G, "program.json")
     with open(path) as f:
         runs = json.load(f)["runs"]
-    assert len(runs) >= 4
+    assert len(runs) >= 20
+    n_aborted = 0
     for run in runs:
         r2 = random.Random(run["input_seed"])
         sp = run["spec"]
         roots = [rand_seq(r2, sp["L"] + 7 * k) for k in range(sp["n_fam"])]
         targets = [(">target_%d family %d" % (k * sp["per"] + j, k), mutate(r2, roots[k], sp["div"])) for k in range(sp["n_fam"]) for j in range(sp["per"])]
         bgs = [(">bg_%d" % i, mutate(r2, roots[i % len(roots)], sp["bg_div"])) for i in range(sp["n_bg"])]
+        if run.get("aborted"):
+            # the reference threw (uncaught inside an OpenMP region: the program dies, its output file is lost): pcr_design reports an error
+            with pytest.raises(api.PcrError):
+                replay(run, targets, bgs)
+            n_aborted += 1
+            continue
         got, pool = replay(run, targets, bgs)
         assert got == run["output"], run["argv"]
+    assert n_aborted <= 3
