@@ -611,6 +611,9 @@ template<class T> struct DevBuf {
 		cap = want;
 		return PCR_OK;
 	}
+	// for lists that grow a little at a time (the irregular words after every batch of splits): a quarter of slack, so that a hipFree +
+	// hipMalloc pair -- a device-wide wait each -- is not paid on every growth
+	int ensure_slack(size_t n) { return (n <= cap) ? PCR_OK : ensure(n + n/4 + 1024); }
 	void release() { if(p){ (void)hipFree(p); p = nullptr; cap = 0; } }
 };
 
@@ -846,6 +849,9 @@ __global__ void k_apply_splits(const uint64_t *__restrict__ where, uint32_t n, u
 
 int upload_irregular(pcr_ctx *ctx, SeqSet &S)
 {
+	const auto tu0 = std::chrono::steady_clock::now();
+	auto ms_since = [&](){ return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tu0).count(); };
+	double t_flat = 0, t_sort = 0, t_scan = 0, t_copy1 = 0;
 	size_t total = 0;
 	for(uint32_t s = 0;s < S.n;++s) total += S.irr_host[s].size();
 	std::vector<IrrDev> flat(total);
@@ -868,16 +874,12 @@ int upload_irregular(pcr_ctx *ctx, SeqSet &S)
 	}
 	off[S.n] = (uint32_t)flat.size();
 	S.n_irr = (uint32_t)flat.size();
+	t_flat = ms_since();
 	// scan order: by size counter, largest first, so that a pass with min_oligo_length m walks a prefix (sequence.cpp:157,239 drop
 	// the words whose counter is below m); equal counters keep the list's order.  A counting sort: the list is rebuilt after every
-	// accepted assay of a design run (pcr_split_many), and a comparison sort of C2's 3e5 words was most of the 280 ms that took.
+	// accepted assay of a design run (pcr_split_many), and a comparison sort of C2's 1.2e6 words was most of the 280 ms that took.
 	std::vector<uint32_t> perm(flat.size());
-	{
-		uint32_t start[256];
-		uint32_t run = 0;
-		for(int k = 255;k >= 0;--k){ start[k] = run; run += S.irr_size_count[k]; }
-		for(size_t i = 0;i < flat.size();++i) perm[start[(flat[i].meta >> 8) & 0xFF]++] = (uint32_t)i;
-	}
+	t_sort = ms_since();
 	int rc;
 	{
 		// bits of a 32-bit plane to the even positions of a 64-bit word
@@ -885,25 +887,36 @@ int upload_irregular(pcr_ctx *ctx, SeqSet &S)
 			v = (v | (v << 16)) & 0x0000FFFF0000FFFFull; v = (v | (v << 8)) & 0x00FF00FF00FF00FFull; v = (v | (v << 4)) & 0x0F0F0F0F0F0F0F0Full;
 			v = (v | (v << 2)) & 0x3333333333333333ull; v = (v | (v << 1)) & 0x5555555555555555ull; return v;
 		};
+		// one pass in list order: a word goes to the next free place of its size counter's run, and its scan record is written there
+		// (reads in sequence, writes into a handful of runs that each grow in sequence; gathering the records in scan order
+		// instead -- a random 48-byte read per word -- was 48 of the 61 ms this took for C2's 1.2e6 words)
+		uint32_t start[256];
+		uint32_t run = 0;
+		for(int k = 255;k >= 0;--k){ start[k] = run; run += S.irr_size_count[k]; }
 		std::vector<IrrScan> scan(perm.size());
-		for(size_t i = 0;i < perm.size();++i){
-			const IrrDev &d = flat[perm[i]];
+		for(size_t i = 0;i < flat.size();++i){
+			const IrrDev &d = flat[i];
+			const uint32_t at = start[(d.meta >> 8) & 0xFF]++;
+			perm[at] = (uint32_t)i;
 			const uint32_t multi = (d.w.a & d.w.c) | (d.w.a & d.w.g) | (d.w.a & d.w.t) | (d.w.c & d.w.g) | (d.w.c & d.w.t) | (d.w.g & d.w.t);
 			const uint32_t lo = d.w.c | d.w.t, hi = d.w.g | d.w.t;             // 2-bit code planes (A,C,G,T = 0..3; empty slots read as A)
 			const uint64_t code = spread(lo) | (spread(hi) << 1);
-			IrrScan r; r.w0 = (uint32_t)code; r.w1 = (uint32_t)(code >> 32); r.idx_flags = perm[i] | (multi ? 0x80000000u : 0u); r.seq = d.seq;
-			scan[i] = r;
+			IrrScan r; r.w0 = (uint32_t)code; r.w1 = (uint32_t)(code >> 32); r.idx_flags = (uint32_t)i | (multi ? 0x80000000u : 0u); r.seq = d.seq;
+			scan[at] = r;
 		}
-		if((rc = S.irr_scan.ensure(scan.size() + 1)) != PCR_OK) return rc;
+		t_scan = ms_since();
+		if((rc = S.irr_scan.ensure_slack(scan.size() + 1)) != PCR_OK) return rc;
 		if(!scan.empty()) HIP_TRY(hipMemcpy(S.irr_scan.p, scan.data(), scan.size()*sizeof(IrrScan), hipMemcpyHostToDevice));
 	}
-	if((rc = S.irr_perm.ensure(perm.size() + 1)) != PCR_OK) return rc;
+	t_copy1 = ms_since();
+	if((rc = S.irr_perm.ensure_slack(perm.size() + 1)) != PCR_OK) return rc;
 	if(!perm.empty()) HIP_TRY(hipMemcpyAsync(S.irr_perm.p, perm.data(), perm.size()*sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-	if((rc = S.irr.ensure(flat.size())) != PCR_OK) return rc;
+	if((rc = S.irr.ensure_slack(flat.size())) != PCR_OK) return rc;
 	if((rc = S.irr_off.ensure(off.size())) != PCR_OK) return rc;
 	if(!flat.empty()) HIP_TRY(hipMemcpyAsync(S.irr.p, flat.data(), flat.size()*sizeof(IrrDev), hipMemcpyHostToDevice, ctx->stream));
 	HIP_TRY(hipMemcpyAsync(S.irr_off.p, off.data(), off.size()*sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
 	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	if(ctx->timing && flat.size() > 100000) fprintf(stderr, "[pcramp] irregular list of %zu words: flat %.1f  order %.1f  scan records %.1f  first copy %.1f  other copies %.1f ms\n", flat.size(), t_flat, t_sort - t_flat, t_scan - t_sort, t_copy1 - t_scan, ms_since() - t_copy1);
 	return PCR_OK;
 }
 
@@ -1647,8 +1660,8 @@ int pcr_split_many(pcr_ctx *ctx, pcr_set which, const uint32_t *seq, const uint6
 	int rc;
 	if(eos_changed) HIP_TRY(hipMemcpyAsync(S.d_has_eos.p, S.has_eos.data(), S.n, hipMemcpyHostToDevice, ctx->stream));
 	// device: clear the bases in their blocks (one launch), refresh the 2 blocks of windows that can see each, redo the irregular
-	// lists of the sequences concerned and upload the set's list ONCE (it is rebuilt whole: sort by size counter, scan records --
-	// 20 ms for C2's 3e5 words, which a design iteration's ~600 splits each paid when this took one split per call)
+	// lists of the sequences concerned and upload the set's list ONCE (it is rebuilt whole: order by size counter, scan records --
+	// tens of ms for C2's 1.2e6 words, which every one of a design iteration's ~70 splits paid when this took one split per call)
 	if((rc = ctx->split_where.ensure(where.size())) != PCR_OK) return rc;
 	HIP_TRY(hipMemcpyAsync(ctx->split_where.p, where.data(), where.size()*sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
 	hipLaunchKernelGGL(k_apply_splits, dim3((n + 255)/256), dim3(256), 0, ctx->stream, ctx->split_where.p, n, (uint32_t *)S.planes.p, S.nib.p);
