@@ -426,7 +426,32 @@ def secondary_figures(api, synth, W, dev, stream, wl_single, scr0, pa, thr):
             t0 = time.perf_counter()
             _, _, iters = moves.optimize_batch(s, trial, **kw)
             dt = time.perf_counter() - t0
-            out["optimize_batch"] = {"assays": n_trial, "targets": wl["T"], "backgrounds": nbg, "ms_per_assay": dt / n_trial * 1e3,
+            # the kernels of that call, from the committed rocprofv3 passes of profiles/dbg/opt_prof.py (trace + counters; static: a profiler
+            # cannot run inside this process): time per launch, VALU issue share at 4 clk per wave instruction, share of the wave cycles parked
+            opt_roof = None
+            try:
+                pj = load_profile_json("%s_optimize_batch_pmc.json" % PROFILE_ROUND) or {}
+                rows = {}
+                with open(os.path.join(ROOT, "profiles", "%s_optimize_batch_stats.md" % PROFILE_ROUND)) as f:
+                    for line in f:
+                        c = [x.strip() for x in line.strip().strip("|").split("|")]
+                        if len(c) >= 4 and c[0] not in ("kernel", "---") and not c[0].startswith("-"):
+                            try:
+                                rows[c[0]] = (int(c[1]), float(c[2]))
+                            except ValueError:
+                                pass
+                opt_roof = {"bound": "valu / LDS and memory latency (see parked share)", "source": "profiles/%s_optimize_batch_{stats.md,pmc.json} (static)" % PROFILE_ROUND,
+                            "model": "SQ_INSTS_VALU x 4 clk / (1024 SIMDs x 2.4 GHz) / mean launch time", "kernels": {}}
+                for k in ("k_pair_moves_lds<true>", "k_pair_moves_tasks", "k_match_t", "thermo::k_thermo_wave", "k_cov_from_bits"):
+                    if k in rows and k in pj and pj[k].get("SQ_INSTS_VALU"):
+                        us = rows[k][1]
+                        insts = pj[k]["SQ_INSTS_VALU"]
+                        opt_roof["kernels"][k] = {"launches_profiled": rows[k][0], "us_per_launch": us,
+                                                  "valu_frac": insts * 4.0 / (N_SIMD * VALU_CLOCK_GHZ * 1e9) / (us * 1e-6),
+                                                  "wave_cycles_parked_on_waitcnt": (pj[k].get("SQ_WAIT_ANY") / pj[k]["SQ_WAVE_CYCLES"]) if pj[k].get("SQ_WAVE_CYCLES") else None}
+            except Exception:                                          # noqa: BLE001
+                opt_roof = None
+            out["optimize_batch"] = {"assays": n_trial, "targets": wl["T"], "backgrounds": nbg, "ms_per_assay": dt / n_trial * 1e3, "roofline": opt_roof,
                                      "ms_total": dt * 1e3, "ms_total_first_call": dt_first * 1e3, "optimiser_iterations_max": max(iters), "optimiser_iterations_mean": sum(iters) / len(iters),
                                      "note": "all trial assays in lockstep: one thermodynamics launch and one move-coverage pass per set per iteration"}
         except Exception as e:                                         # noqa: BLE001
