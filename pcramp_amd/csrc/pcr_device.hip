@@ -737,6 +737,7 @@ struct pcr_ctx {
 	DevBuf<thermo::Job> th_jobs; DevBuf<thermo::JobOut> th_out; DevBuf<int> th_dg; DevBuf<uint2> th_map; DevBuf<uint32_t> th_bad;
 	float th_dg_salt = -1.0f;   // salt the table in th_dg was built for
 	DevBuf<unsigned long long> th_dbg; bool th_attr_set = false;
+	std::vector<thermo::Job> th_host_jobs; std::vector<thermo::JobOut> th_host_res;   // pcr_thermo's job records and results, kept between calls
 	uint8_t *sw_pin = nullptr, *sw_pin_dev = nullptr; hipEvent_t sw_done[2] = {nullptr, nullptr};   // pcr_sw_align_words: two pinned chunk buffers (words in, results out)
 	DevBuf<pcr_amplicon> mx_amp;   // pcr_collect_amplicons records
 	DevBuf<OligoDev> opt_oligos; DevBuf<uint2> opt_jobs; DevBuf<float> opt_cov; DevBuf<uint32_t> opt_loc, opt_tasks;   // pcr_optimize_batch: base oligos + trial words, per-oligo variant ranges, coverages
