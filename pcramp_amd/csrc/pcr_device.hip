@@ -642,6 +642,8 @@ struct SeqSet {
 	std::vector<uint8_t> has_eos; DevBuf<uint8_t> d_has_eos;   // sequence holds an EOS nibble (record padding, splits): only then has_split has to look
 	DevBuf<IrrDev> irr;
 	DevBuf<IrrScan> irr_scan;     // the irregular words in scan order with their 2-bit codes (k_seed2)
+	DevBuf<uint32_t> irx_first, irx_last, irx_words, irx_sums; bool irx_valid = false;   // their inverse index (pcr_scan_seed2.inc), built on demand
+	uint32_t irr_n_multi = 0;     // irregular words holding an IUPAC slot (they meet every candidate: no index for them)
 	DevBuf<uint8_t> codes; DevBuf<uint64_t> d_code_off; bool have_codes = false;
 	// word DB of the last select
 	bool have_db = false;
@@ -656,7 +658,7 @@ struct SeqSet {
 	uint32_t *d_seg_hi = nullptr;
 	void release()
 	{
-		d_weight.release(); tile_desc.release(); irr_scan.release(); irr_perm.release(); planes.release(); valid.release(); nib.release(); tb.release(); degen_tiles.release(); tile_degen.release(); blk_seq.release(); tile_seq.release(); tile_pos0.release();
+		d_weight.release(); tile_desc.release(); irr_scan.release(); irx_first.release(); irx_last.release(); irx_words.release(); irx_sums.release(); irr_perm.release(); planes.release(); valid.release(); nib.release(); tb.release(); degen_tiles.release(); tile_degen.release(); blk_seq.release(); tile_seq.release(); tile_pos0.release();
 		irr_off.release(); d_len.release(); d_blk_off.release();
 		d_nblk_real.release(); d_active.release(); d_has_eos.release(); irr.release(); db.release(); touched.release(); ctrl.release(); codes.release(); d_code_off.release();
 	}
@@ -723,7 +725,7 @@ struct pcr_ctx {
 	struct S2Entry { std::vector<uint32_t> seeds; /* code << 14 | off << 9 */ uint32_t off_mask; bool seedable; };
 	std::unordered_map<S2Key, S2Entry, S2KeyHash> s2_cache;
 	std::vector<pcrhost::Seed> s2_tmp;
-	bool s2_attr_set = false; uint32_t s2_dbg = 0;
+	bool s2_attr_set = false; uint32_t s2_dbg = 0; bool no_irr_index = false;   // PCRAMP_IRR_INDEX=0: the irregular words scanned in chunks by every wave (A/B)
 	// first form, tables built on the device (k_seed_tables): the pass's seed list, its own per-oligo cache (8-gram seeds), the tables
 	std::vector<uint32_t> s1_seeds; std::unordered_map<S2Key, S2Entry, S2KeyHash> s1_cache;
 	DevBuf<uint32_t> s1_image, s1_heads, s1_multi, s1_part;
@@ -895,16 +897,19 @@ int upload_irregular(pcr_ctx *ctx, SeqSet &S)
 		uint32_t run = 0;
 		for(int k = 255;k >= 0;--k){ start[k] = run; run += S.irr_size_count[k]; }
 		std::vector<IrrScan> scan(perm.size());
+		uint32_t n_multi = 0;
 		for(size_t i = 0;i < flat.size();++i){
 			const IrrDev &d = flat[i];
 			const uint32_t at = start[(d.meta >> 8) & 0xFF]++;
 			perm[at] = (uint32_t)i;
 			const uint32_t multi = (d.w.a & d.w.c) | (d.w.a & d.w.g) | (d.w.a & d.w.t) | (d.w.c & d.w.g) | (d.w.c & d.w.t) | (d.w.g & d.w.t);
+			if(multi) ++n_multi;
 			const uint32_t lo = d.w.c | d.w.t, hi = d.w.g | d.w.t;             // 2-bit code planes (A,C,G,T = 0..3; empty slots read as A)
 			const uint64_t code = spread(lo) | (spread(hi) << 1);
 			IrrScan r; r.w0 = (uint32_t)code; r.w1 = (uint32_t)(code >> 32); r.idx_flags = (uint32_t)i | (multi ? 0x80000000u : 0u); r.seq = d.seq;
 			scan[at] = r;
 		}
+		S.irr_n_multi = n_multi; S.irx_valid = false;
 		t_scan = ms_since();
 		if((rc = S.irr_scan.ensure_slack(scan.size() + 1)) != PCR_OK) return rc;
 		if(!scan.empty()) HIP_TRY(hipMemcpy(S.irr_scan.p, scan.data(), scan.size()*sizeof(IrrScan), hipMemcpyHostToDevice));
@@ -918,6 +923,34 @@ int upload_irregular(pcr_ctx *ctx, SeqSet &S)
 	HIP_TRY(hipMemcpyAsync(S.irr_off.p, off.data(), off.size()*sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
 	HIP_TRY(hipStreamSynchronize(ctx->stream));
 	if(ctx->timing && flat.size() > 100000) fprintf(stderr, "[pcramp] irregular list of %zu words: flat %.1f  order %.1f  scan records %.1f  first copy %.1f  other copies %.1f ms\n", flat.size(), t_flat, t_sort - t_flat, t_scan - t_sort, t_copy1 - t_scan, ms_since() - t_copy1);
+	return PCR_OK;
+}
+
+// The inverse index of the set's irregular words (pcr_scan_seed2.inc), for the state the set is in: counting sort of (word, slot
+// offset) by the 9-gram read there.  ~1 ms for C2's 1.2e6 words; rebuilt after the irregular list changes (load, splits).
+int ensure_irr_index(pcr_ctx *ctx, SeqSet &S)
+{
+	if(S.irx_valid) return PCR_OK;
+	int rc;
+	if((rc = S.irx_first.ensure(IRX_KEYS + 4)) != PCR_OK) return rc;
+	if((rc = S.irx_last.ensure(IRX_KEYS + 4)) != PCR_OK) return rc;
+	if((rc = S.irx_words.ensure_slack((size_t)24*S.n_irr + 4)) != PCR_OK) return rc;
+	const uint32_t n_blocks = (IRX_KEYS + 4095u)/4096u;                           // 1 536
+	if((rc = S.irx_sums.ensure(n_blocks + 4)) != PCR_OK) return rc;
+	HIP_TRY(hipMemsetAsync(S.irx_last.p, 0, (size_t)IRX_KEYS*sizeof(uint32_t), ctx->stream));   // counts first, ends of the runs in the end
+	if(S.n_irr){
+		hipLaunchKernelGGL(k_irx_count, dim3((S.n_irr + 255)/256), dim3(256), 0, ctx->stream, S.irr.p, S.n_irr, S.irx_last.p);
+		HIP_TRY(hipGetLastError());
+	}
+	hipLaunchKernelGGL(k_scan_blocks, dim3(n_blocks), dim3(1024), 0, ctx->stream, S.irx_last.p, S.irx_first.p, IRX_KEYS, S.irx_sums.p);
+	hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, ctx->stream, S.irx_sums.p, n_blocks);
+	hipLaunchKernelGGL(k_scan_add, dim3(n_blocks), dim3(1024), 0, ctx->stream, S.irx_first.p, S.irx_last.p, IRX_KEYS, S.irx_sums.p);   // first = starts; last = a copy, advanced by the scatter to the ends
+	HIP_TRY(hipGetLastError());
+	if(S.n_irr){
+		hipLaunchKernelGGL(k_irx_scatter, dim3((S.n_irr + 255)/256), dim3(256), 0, ctx->stream, S.irr.p, S.n_irr, S.irx_last.p, S.irx_words.p);
+		HIP_TRY(hipGetLastError());
+	}
+	S.irx_valid = true;
 	return PCR_OK;
 }
 
@@ -1368,6 +1401,7 @@ pcr_ctx *pcr_create(int device, void *hip_stream, const pcr_params *params)
 	if(const char *v = getenv("PCRAMP_SEED")) ctx->force_seed1 = v[0] == '1';
 	if(const char *v = getenv("PCRAMP_SEED_TABLES")) ctx->host_seed_tables = v[0] == 'h';
 	if(const char *v = getenv("PCRAMP_S2DBG")) ctx->s2_dbg = (uint32_t)atoi(v);
+	if(const char *v = getenv("PCRAMP_IRR_INDEX")) ctx->no_irr_index = v[0] == '0';
 	if(const char *v = getenv("PCRAMP_SCAN")){ if(v[0] == '1') ctx->scan_version = 1; else if(v[0] == '2') ctx->scan_version = 2; }   // A/B: 1 = popcount scan, 2 = bit-sliced only
 	{
 		// direct staging: fine-grained device memory the CPU can store into (large BAR) and whose stores a later launch sees.
@@ -1447,7 +1481,7 @@ void pcr_destroy(pcr_ctx *ctx)
 	if(ctx->sw_pin) (void)hipHostFree(ctx->sw_pin);
 	for(int k = 0;k < 2;++k){ if(ctx->sw_done[k]) (void)hipEventDestroy(ctx->sw_done[k]); }
 	ctx->oligos.release(); ctx->sw_jobs.release(); ctx->sw_out.release(); ctx->sw_q.release(); ctx->sw_qlen.release(); ctx->sw_t.release(); ctx->entry_codes.release(); ctx->entry_lens.release(); ctx->amp_recs.release(); ctx->amp_recs2.release(); ctx->amp_keys.release(); ctx->amp_pkeys.release(); ctx->amp_pair_start.release(); ctx->sort_tmp.release(); ctx->bg_pairs.release(); ctx->th_jobs.release(); ctx->th_out.release(); ctx->th_dg.release(); ctx->th_dbg.release(); ctx->split_where.release(); ctx->th_map.release(); ctx->th_bad.release(); ctx->mx_keys.release(); ctx->mx_count.release(); ctx->mx_amp.release(); ctx->opt_oligos.release(); ctx->opt_jobs.release(); ctx->opt_cov.release(); ctx->opt_loc.release(); ctx->opt_tasks.release();
-	if(ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
+	if(ctx->aux_stream){ (void)hipStreamSynchronize(ctx->aux_stream); (void)hipStreamDestroy(ctx->aux_stream); }
 	if(ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
@@ -2175,6 +2209,9 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 					}
 					uint32_t g_begin = 0;
 					bool first_launch = true;
+					bool irr_by_index = or_plain.empty() && S.irr_n_multi == 0 && n_live > 0 && !ctx->no_irr_index;
+					for(size_t g = 0, b = 0;g < ctx->s2_group_end.size();++g){ if((size_t)ctx->s2_group_end[g] - b > (size_t)sgrid.x*S2_THREADS) irr_by_index = false; b = ctx->s2_group_end[g]; }   // (a thread looks up at most one seed)
+					if(irr_by_index && (rc = ensure_irr_index(ctx, S)) != PCR_OK) return rc;
 					for(size_t g = 0;g < ctx->s2_group_end.size();++g){
 						Seed2Tables Tg = ST2;
 						const uint32_t or0 = ctx->s2_group_or[g], g_or = ctx->s2_group_nor[g];
@@ -2186,9 +2223,13 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 						IrrArgs2 IA; IA.scan = S.irr_scan.p; IA.irr = S.irr.p; IA.n_live = n_live;
 						IA.off_mask = ctx->s2_group_offmask[g];
 						IA.exhaustive = first_launch ? 1u : 0u;                             // words holding IUPAC slots meet every candidate once, in the first launch
+						IA.ix_first = IA.ix_last = IA.ix_words = nullptr; IA.min_cws = std::min<uint32_t>(min_oligo_length, 255u);
 						if(!or_plain.empty()){                                              // unseeded candidates in the pass: every irregular word meets every candidate, once
 							IA.off_mask = 0;
 							if(!first_launch) IA.n_live = 0;
+						}
+						else if(irr_by_index){                                               // every candidate seeded, no IUPAC word in the set: the words come in through the index, by seed
+							IA.ix_first = S.irx_first.p; IA.ix_last = S.irx_last.p; IA.ix_words = S.irx_words.p; IA.n_live = 0;
 						}
 						if(getenv("PCRAMP_DEBUG")) fprintf(stderr, "[pcramp] k_seed2: %u workgroups, %u seeds of orientations %u..%u (group %zu of %zu), %zu + %zu B of LDS\n", sgrid.x, Tg.n_seeds,
 							or0, or0 + g_or - 1, g + 1, ctx->s2_group_end.size(), sizeof(S2Shared), dyn);
