@@ -2209,7 +2209,7 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 					}
 					uint32_t g_begin = 0;
 					bool first_launch = true;
-					bool irr_by_index = or_plain.empty() && S.irr_n_multi == 0 && n_live > 0 && !ctx->no_irr_index;
+					bool irr_by_index = or_plain.empty() && S.irr_n_multi == 0 && n_live > 0 && !ctx->no_irr_index && (uint64_t)24*S.n_irr < (uint64_t(1) << 32);   // (the index counts its entries in 32 bits)
 					for(size_t g = 0, b = 0;g < ctx->s2_group_end.size();++g){ if((size_t)ctx->s2_group_end[g] - b > (size_t)sgrid.x*S2_THREADS) irr_by_index = false; b = ctx->s2_group_end[g]; }   // (a thread looks up at most one seed)
 					if(irr_by_index && (rc = ensure_irr_index(ctx, S)) != PCR_OK) return rc;
 					for(size_t g = 0;g < ctx->s2_group_end.size();++g){
