@@ -642,7 +642,7 @@ struct SeqSet {
 	std::vector<uint8_t> has_eos; DevBuf<uint8_t> d_has_eos;   // sequence holds an EOS nibble (record padding, splits): only then has_split has to look
 	DevBuf<IrrDev> irr;
 	DevBuf<IrrScan> irr_scan;     // the irregular words in scan order with their 2-bit codes (k_seed2)
-	DevBuf<uint32_t> irx_first, irx_last, irx_words, irx_sums; bool irx_valid = false;   // their inverse index (pcr_scan_seed2.inc), built on demand
+	DevBuf<uint32_t> irx_first, irx_last, irx_words, irx_sums; bool irx_valid = false, irx_usable = false;   // their inverse index (pcr_scan_seed2.inc), built on demand; usable: no key's run is longer than IRX_MAX_RUN
 	uint32_t irr_n_multi = 0;     // irregular words holding an IUPAC slot (they meet every candidate: no index for them)
 	DevBuf<uint8_t> codes; DevBuf<uint64_t> d_code_off; bool have_codes = false;
 	// word DB of the last select
@@ -928,6 +928,7 @@ int upload_irregular(pcr_ctx *ctx, SeqSet &S)
 
 // The inverse index of the set's irregular words (pcr_scan_seed2.inc), for the state the set is in: counting sort of (word, slot
 // offset) by the 9-gram read there.  ~1 ms for C2's 1.2e6 words; rebuilt after the irregular list changes (load, splits).
+constexpr uint32_t IRX_MAX_RUN = 1024;
 int ensure_irr_index(pcr_ctx *ctx, SeqSet &S)
 {
 	if(S.irx_valid) return PCR_OK;
@@ -941,6 +942,16 @@ int ensure_irr_index(pcr_ctx *ctx, SeqSet &S)
 	if(S.n_irr){
 		hipLaunchKernelGGL(k_irx_count, dim3((S.n_irr + 255)/256), dim3(256), 0, ctx->stream, S.irr.p, S.n_irr, S.irx_last.p);
 		HIP_TRY(hipGetLastError());
+	}
+	{
+		// a key shared by more words than a wave should walk (IRX_MAX_RUN): the set keeps the chunk form of the irregular scan
+		uint32_t longest = 0;
+		HIP_TRY(hipMemsetAsync(S.irx_sums.p + n_blocks, 0, sizeof(uint32_t), ctx->stream));
+		hipLaunchKernelGGL(k_irx_max, dim3(256), dim3(256), 0, ctx->stream, S.irx_last.p, IRX_KEYS, S.irx_sums.p + n_blocks);
+		HIP_TRY(hipMemcpyAsync(&longest, S.irx_sums.p + n_blocks, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(hipStreamSynchronize(ctx->stream));
+		S.irx_usable = longest <= IRX_MAX_RUN;
+		if(!S.irx_usable){ S.irx_valid = true; return PCR_OK; }
 	}
 	hipLaunchKernelGGL(k_scan_blocks, dim3(n_blocks), dim3(1024), 0, ctx->stream, S.irx_last.p, S.irx_first.p, IRX_KEYS, S.irx_sums.p);
 	hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, ctx->stream, S.irx_sums.p, n_blocks);
@@ -2211,7 +2222,7 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 					bool first_launch = true;
 					bool irr_by_index = or_plain.empty() && S.irr_n_multi == 0 && n_live > 0 && !ctx->no_irr_index && (uint64_t)24*S.n_irr < (uint64_t(1) << 32);   // (the index counts its entries in 32 bits)
 					for(size_t g = 0, b = 0;g < ctx->s2_group_end.size();++g){ if((size_t)ctx->s2_group_end[g] - b > (size_t)sgrid.x*S2_THREADS) irr_by_index = false; b = ctx->s2_group_end[g]; }   // (a thread looks up at most one seed)
-					if(irr_by_index && (rc = ensure_irr_index(ctx, S)) != PCR_OK) return rc;
+					if(irr_by_index){ if((rc = ensure_irr_index(ctx, S)) != PCR_OK) return rc; irr_by_index = S.irx_usable; }
 					for(size_t g = 0;g < ctx->s2_group_end.size();++g){
 						Seed2Tables Tg = ST2;
 						const uint32_t or0 = ctx->s2_group_or[g], g_or = ctx->s2_group_nor[g];
