@@ -385,6 +385,7 @@ __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_AC
 #include "pcr_scan_bitsliced.inc"
 #include "pcr_scan_seed.inc"
 #include "pcr_scan_seed2.inc"
+#include "pcr_scan_seed3.inc"
 
 // One workgroup per sequence: keep the hits that attain the final per-(sequence,candidate) maximum
 // (select_words.cpp:100-117), sort them by (loc, strand, kind, ord) (bitonic, LDS), drop duplicates
@@ -644,6 +645,8 @@ struct SeqSet {
 	DevBuf<IrrScan> irr_scan;     // the irregular words in scan order with their 2-bit codes (k_seed2)
 	DevBuf<uint32_t> irx_first, irx_last, irx_words, irx_sums; bool irx_valid = false, irx_usable = false;   // their inverse index (pcr_scan_seed2.inc), built on demand; usable: no key's run is longer than IRX_MAX_RUN
 	uint32_t irr_n_multi = 0;     // irregular words holding an IUPAC slot (they meet every candidate: no index for them)
+	// the positions of the set by the 9-gram that starts there (pcr_scan_seed3.inc), built on demand after a load
+	DevBuf<uint32_t> pix_first, pix_last, pix_pos, pix_sums, seq_tile0; DevBuf<uint4> pix_ctx; std::vector<uint32_t> pix_count_h; uint64_t pix_generation = 0; bool pix_valid = false, pix_usable = false;
 	DevBuf<uint8_t> codes; DevBuf<uint64_t> d_code_off; bool have_codes = false;
 	// word DB of the last select
 	bool have_db = false;
@@ -658,7 +661,7 @@ struct SeqSet {
 	uint32_t *d_seg_hi = nullptr;
 	void release()
 	{
-		d_weight.release(); tile_desc.release(); irr_scan.release(); irx_first.release(); irx_last.release(); irx_words.release(); irx_sums.release(); irr_perm.release(); planes.release(); valid.release(); nib.release(); tb.release(); degen_tiles.release(); tile_degen.release(); blk_seq.release(); tile_seq.release(); tile_pos0.release();
+		d_weight.release(); tile_desc.release(); irr_scan.release(); irx_first.release(); irx_last.release(); irx_words.release(); irx_sums.release(); pix_first.release(); pix_last.release(); pix_pos.release(); pix_ctx.release(); pix_sums.release(); seq_tile0.release(); irr_perm.release(); planes.release(); valid.release(); nib.release(); tb.release(); degen_tiles.release(); tile_degen.release(); blk_seq.release(); tile_seq.release(); tile_pos0.release();
 		irr_off.release(); d_len.release(); d_blk_off.release();
 		d_nblk_real.release(); d_active.release(); d_has_eos.release(); irr.release(); db.release(); touched.release(); ctrl.release(); codes.release(); d_code_off.release();
 	}
@@ -722,9 +725,11 @@ struct pcr_ctx {
 	std::vector<uint32_t> s2_group_end, s2_group_offmask, s2_group_or, s2_group_nor;   // per group: end in the seed list, forward-seed slot offsets, first orientation, orientations spanned   // the seed list in groups of whole orientations, each within one launch's LDS budget
 	struct S2Key { uint32_t a, c, g, t, floor_; bool operator==(const S2Key &o) const { return a == o.a && c == o.c && g == o.g && t == o.t && floor_ == o.floor_; } };
 	struct S2KeyHash { size_t operator()(const S2Key &k) const { uint64_t h = 0x9E3779B97F4A7C15ull; for(uint32_t v : {k.a, k.c, k.g, k.t, k.floor_}){ h ^= v; h *= 0x100000001B3ull; h ^= h >> 29; } return (size_t)h; } };
-	struct S2Entry { std::vector<uint32_t> seeds; /* code << 14 | off << 9 */ uint32_t off_mask; bool seedable; };
+	struct S2Entry { std::vector<uint32_t> seeds; /* code << 14 | off << 9 */ uint32_t off_mask; bool seedable;
+		std::vector<uint32_t> chunks; uint64_t chunks_gen = 0; /* third form: 64-entry chunks of the seeds' runs in the set whose position index has this generation */ };
 	std::unordered_map<S2Key, S2Entry, S2KeyHash> s2_cache;
 	std::vector<pcrhost::Seed> s2_tmp;
+	std::vector<uint32_t> s3_prefix; bool no_seed3 = false, s3_attr_set = false;   // third form: the pass's chunk list; PCRAMP_SEED3=0: second form (A/B)
 	bool s2_attr_set = false; uint32_t s2_dbg = 0; bool no_irr_index = false;   // PCRAMP_IRR_INDEX=0: the irregular words scanned in chunks by every wave (A/B)
 	// first form, tables built on the device (k_seed_tables): the pass's seed list, its own per-oligo cache (8-gram seeds), the tables
 	std::vector<uint32_t> s1_seeds; std::unordered_map<S2Key, S2Entry, S2KeyHash> s1_cache;
@@ -962,6 +967,42 @@ int ensure_irr_index(pcr_ctx *ctx, SeqSet &S)
 		HIP_TRY(hipGetLastError());
 	}
 	S.irx_valid = true;
+	return PCR_OK;
+}
+
+// The set's positions by the 9-gram that starts there (pcr_scan_seed3.inc), each with the 64 bases around it: counting sort on the
+// device.  20 bytes per base; built once per load.
+int ensure_pos_index(pcr_ctx *ctx, SeqSet &S)
+{
+	if(S.pix_valid) return PCR_OK;
+	S.pix_valid = true; S.pix_usable = false;
+	if(S.total_blocks == 0 || S.total_blocks*32 >= (uint64_t(1) << 32) - 64) return PCR_OK;   // positions are 32-bit
+	int rc;
+	if((rc = S.pix_first.ensure(PIX_CODES + 4)) != PCR_OK) return rc;
+	if((rc = S.pix_last.ensure(PIX_CODES + 4)) != PCR_OK) return rc;
+	const uint32_t n_blocks = (PIX_CODES + 4095u)/4096u;
+	if((rc = S.pix_sums.ensure(n_blocks + 4)) != PCR_OK) return rc;
+	if((rc = S.pix_pos.ensure(S.total_blocks*32 + 64)) != PCR_OK) return rc;
+	if((rc = S.pix_ctx.ensure(S.total_blocks*32 + 64)) != PCR_OK) return rc;
+	HIP_TRY(hipMemsetAsync(S.pix_last.p, 0, (size_t)PIX_CODES*sizeof(uint32_t), ctx->stream));
+	const unsigned grid = (unsigned)((S.total_blocks + 255)/256);
+	hipLaunchKernelGGL(k_pix_build<false>, dim3(grid), dim3(256), 0, ctx->stream, S.tb_d(), S.blk_seq.p, S.d_blk_off.p, S.d_len.p, S.total_blocks, S.pix_last.p, (uint32_t *)nullptr, (uint4 *)nullptr);
+	hipLaunchKernelGGL(k_scan_blocks, dim3(n_blocks), dim3(1024), 0, ctx->stream, S.pix_last.p, S.pix_first.p, PIX_CODES, S.pix_sums.p);
+	hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, ctx->stream, S.pix_sums.p, n_blocks);
+	hipLaunchKernelGGL(k_scan_add, dim3(n_blocks), dim3(1024), 0, ctx->stream, S.pix_first.p, S.pix_last.p, PIX_CODES, S.pix_sums.p);
+	hipLaunchKernelGGL(k_pix_build<true>, dim3(grid), dim3(256), 0, ctx->stream, S.tb_d(), S.blk_seq.p, S.d_blk_off.p, S.d_len.p, S.total_blocks, S.pix_last.p, S.pix_pos.p, S.pix_ctx.p);
+	HIP_TRY(hipGetLastError());
+	{
+		std::vector<uint32_t> first(PIX_CODES), last(PIX_CODES);
+		HIP_TRY(hipMemcpyAsync(first.data(), S.pix_first.p, (size_t)PIX_CODES*sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(hipMemcpyAsync(last.data(), S.pix_last.p, (size_t)PIX_CODES*sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(hipStreamSynchronize(ctx->stream));
+		S.pix_count_h.resize(PIX_CODES);
+		for(uint32_t c = 0;c < PIX_CODES;++c) S.pix_count_h[c] = last[c] - first[c];
+		static uint64_t generations = 0;
+		S.pix_generation = ++generations;
+	}
+	S.pix_usable = true;
 	return PCR_OK;
 }
 
@@ -1413,6 +1454,7 @@ pcr_ctx *pcr_create(int device, void *hip_stream, const pcr_params *params)
 	if(const char *v = getenv("PCRAMP_SEED_TABLES")) ctx->host_seed_tables = v[0] == 'h';
 	if(const char *v = getenv("PCRAMP_S2DBG")) ctx->s2_dbg = (uint32_t)atoi(v);
 	if(const char *v = getenv("PCRAMP_IRR_INDEX")) ctx->no_irr_index = v[0] == '0';
+	if(const char *v = getenv("PCRAMP_SEED3")) ctx->no_seed3 = v[0] == '0';
 	if(const char *v = getenv("PCRAMP_SCAN")){ if(v[0] == '1') ctx->scan_version = 1; else if(v[0] == '2') ctx->scan_version = 2; }   // A/B: 1 = popcount scan, 2 = bit-sliced only
 	{
 		// direct staging: fine-grained device memory the CPU can store into (large BAR) and whose stores a later launch sees.
@@ -1576,9 +1618,11 @@ static int load_sequences_impl(pcr_ctx *ctx, int which, const uint8_t *packed4, 
 	S.n_tiles = (uint32_t)n_tiles;
 
 	// host-side index pieces: block -> sequence map, tile list, irregular words
-	std::vector<uint32_t> blk_seq(total_blocks), tile_seq(n_tiles), tile_pos0(n_tiles);
+	std::vector<uint32_t> blk_seq(total_blocks), tile_seq(n_tiles), tile_pos0(n_tiles), seq_tile0((size_t)n + 1, 0);
 	uint64_t t = 0;
+	S.pix_valid = false; S.pix_usable = false;
 	for(uint32_t s = 0;s < n;++s){
+		seq_tile0[s] = (uint32_t)t;
 		for(uint64_t b = S.blk_off[s];b < S.blk_off[s + 1];++b) blk_seq[b] = s;
 		if(lengths[s] >= 32){
 			const uint64_t nt = (lengths[s] - 7 + TILE_POS - 1)/TILE_POS;
@@ -1618,6 +1662,8 @@ static int load_sequences_impl(pcr_ctx *ctx, int which, const uint8_t *packed4, 
 	}
 	H2D(d_byte_off.p, dev_byte_off.data(), n*sizeof(uint64_t));
 	H2D(S.blk_seq.p, blk_seq.data(), total_blocks*sizeof(uint32_t));
+	if((rc = S.seq_tile0.ensure((size_t)n + 1)) != PCR_OK) return fail(rc);
+	H2D(S.seq_tile0.p, seq_tile0.data(), ((size_t)n + 1)*sizeof(uint32_t));
 	H2D(S.tile_seq.p, tile_seq.data(), n_tiles*sizeof(uint32_t));
 	H2D(S.tile_pos0.p, tile_pos0.data(), n_tiles*sizeof(uint32_t));
 	H2D(S.d_len.p, S.len.data(), n*sizeof(uint64_t));
@@ -2048,6 +2094,48 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 		if(use_seed2 && !or_plain.empty() && (n_or <= S1_MAX_OR || or_seed.empty())) use_seed2 = false;
 		if(!use_seed2){ or_seed.clear(); or_plain.clear(); irr_off_mask = 0; }
 	}
+	// ... and the third form -- the targets' positions indexed by their 9-grams, the seeds looked up (pcr_scan_seed3.inc) -- where every
+	// candidate is seeded and the irregular words can come in through their index too
+	bool use_seed3 = false;
+	if(use_seed2 && or_plain.empty() && !or_seed.empty() && !ctx->no_seed3 && !ctx->no_irr_index && ctx->s2_dbg == 0){
+		int irc = ensure_pos_index(ctx, S);
+		if(irc != PCR_OK) return irc;
+		uint32_t n_live0 = 0;
+		for(uint32_t k = std::min<uint32_t>(min_oligo_length, 256);k < 256;++k) n_live0 += S.irr_size_count[k];
+		bool irr_ok = n_live0 == 0;
+		if(!irr_ok && S.irr_n_multi == 0 && (uint64_t)24*S.n_irr < (uint64_t(1) << 32)){
+			if((irc = ensure_irr_index(ctx, S)) != PCR_OK) return irc;
+			irr_ok = S.irx_usable;
+		}
+		use_seed3 = S.pix_usable && irr_ok;
+		if(use_seed3){
+			// the chunk list of every launch group: the running number of 64-entry chunks of its seeds' runs.  The seed list is the
+			// seeded orientations' cached lists one after the other (plan_seed2), so are the chunk counts, cached beside them per oligo
+			// for the set last used (a look-up of the run lengths per seed was 20 us of host time per pass)
+			std::vector<uint32_t> &pf = ctx->s3_prefix;
+			pf.clear();
+			size_t si = 0, g = 0;
+			uint64_t run = 0;
+			for(uint32_t o : or_seed){
+				const pcrhost::Candidate &c = cand[o >> 1];
+				const Planes &m = (o & 1u) ? c.rc : c.fwd;
+				const pcr_ctx::S2Key key = {m.a, m.c, m.g, m.t, c.floor_};
+				pcr_ctx::S2Entry &e = ctx->s2_cache.find(key)->second;               // (plan_seed2 has just put it there)
+				if(e.chunks_gen != S.pix_generation){
+					e.chunks.resize(e.seeds.size());
+					for(size_t k = 0;k < e.seeds.size();++k) e.chunks[k] = (S.pix_count_h[e.seeds[k] >> 14] + 63u) >> 6;
+					e.chunks_gen = S.pix_generation;
+				}
+				for(size_t k = 0;k < e.chunks.size();++k, ++si){
+					while(g < ctx->s2_group_end.size() && si == ctx->s2_group_end[g]){ pf.push_back((uint32_t)run); run = 0; ++g; }   // a group ends: its total, then the next one starts at 0
+					pf.push_back((uint32_t)run);
+					run += e.chunks[k];
+				}
+			}
+			pf.push_back((uint32_t)run);
+			if(si != ctx->s2_seeds.size() || pf.size() != ctx->s2_seeds.size() + ctx->s2_group_end.size()) use_seed3 = false;   // (the lists disagree: keep the second form)
+		}
+	}
 	bool dev_tables = false;                           // first form, tables built by k_seed_tables
 	if(!use_seed2 && ctx->scan_version == 3 && !ctx->host_seed_tables && !optimize_5 && !optimize_3 && n_or <= S1_MAX_OR){
 		plan_seed1(ctx, cand, or_seed, or_plain, irr_off_mask);
@@ -2063,6 +2151,7 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 	else{ for(uint32_t o = 0;o < n_or;++o) or_plain.push_back(o); }
 	SeedTables ST; memset(&ST, 0, sizeof(ST));
 	Seed2Tables ST2; memset(&ST2, 0, sizeof(ST2));
+	const uint32_t *d_s3_prefix = nullptr;
 	const size_t n_seeds = use_seed2 ? ctx->s2_seeds.size() : dev_tables ? ctx->s1_seeds.size() : H.seeds.size() + H.n_inherited;
 	if(getenv("PCRAMP_DEBUG")) fprintf(stderr, "[pcramp] scan plan: %u candidates, %zu seeded orientations (%zu seeds), %zu plain, %u/%u IUPAC tiles, %u-slot buckets\n",
 		ncand, or_seed.size(), n_seeds, or_plain.size(), S.n_degen_tiles, S.n_tiles, S.bucket_cap);
@@ -2091,6 +2180,7 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 				floors2[o] = (uint8_t)std::min<uint32_t>(cand[o >> 1].floor_, 255u);
 			}
 			bytes += masks2.size()*sizeof(uint4) + floors2.size() + ctx->s2_seeds.size()*sizeof(uint32_t) + 512;
+			if(use_seed3) bytes += ctx->s3_prefix.size()*sizeof(uint32_t) + 64;
 		}
 		const bool build_tables = dev_tables && !or_seed.empty();
 		if(build_tables) bytes += ctx->s1_seeds.size()*sizeof(uint32_t) + 256;
@@ -2150,6 +2240,7 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 			ST2.masks = st.put(masks2.data(), masks2.size());
 			ST2.floors = st.put(floors2.data(), floors2.size());
 			ST2.n_seeds = (uint32_t)ctx->s2_seeds.size(); ST2.n_or = n_or;
+			if(use_seed3) d_s3_prefix = st.put(ctx->s3_prefix.data(), ctx->s3_prefix.size());
 		}
 		// the staging launch also clears the control block and the result bitsets -- unless the pass is lean: then the tables
 		// are already in device memory, the control block was left clean by the previous pass's tail and k_seed2 clears the bitsets
@@ -2218,18 +2309,19 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 						HIP_TRY(hipFuncSetAttribute((const void *)k_seed2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160*1024 - sizeof(S2Shared))));
 						ctx->s2_attr_set = true;
 					}
-					uint32_t g_begin = 0;
+					uint32_t g_begin = 0, g_prefix = 0;
 					bool first_launch = true;
 					bool irr_by_index = or_plain.empty() && S.irr_n_multi == 0 && n_live > 0 && !ctx->no_irr_index && (uint64_t)24*S.n_irr < (uint64_t(1) << 32);   // (the index counts its entries in 32 bits)
 					for(size_t g = 0, b = 0;g < ctx->s2_group_end.size();++g){ if((size_t)ctx->s2_group_end[g] - b > (size_t)sgrid.x*S2_THREADS) irr_by_index = false; b = ctx->s2_group_end[g]; }   // (a thread looks up at most one seed)
 					if(irr_by_index){ if((rc = ensure_irr_index(ctx, S)) != PCR_OK) return rc; irr_by_index = S.irx_usable; }
+					if(use_seed3) irr_by_index = n_live > 0;                                 // (decided with the form: the index is there and usable)
 					for(size_t g = 0;g < ctx->s2_group_end.size();++g){
 						Seed2Tables Tg = ST2;
 						const uint32_t or0 = ctx->s2_group_or[g], g_or = ctx->s2_group_nor[g];
 						Tg.seeds = ST2.seeds + g_begin; Tg.n_seeds = ctx->s2_group_end[g] - g_begin;
 						Tg.masks = ST2.masks + (size_t)or0; Tg.floors = ST2.floors + or0; Tg.n_or = g_or; Tg.or_base = or0;
 						g_begin = ctx->s2_group_end[g];
-						if(Tg.n_seeds == 0) continue;
+						if(Tg.n_seeds == 0){ g_prefix += 1u; continue; }
 						const size_t dyn = (size_t)g_or*sizeof(uint4) + (((size_t)g_or + 15) & ~size_t(15)) + 8*((size_t)Tg.n_seeds + 64) + 16;   // masks | floors | chain | head (each with 64 dummy slots)
 						IrrArgs2 IA; IA.scan = S.irr_scan.p; IA.irr = S.irr.p; IA.n_live = n_live;
 						IA.off_mask = ctx->s2_group_offmask[g];
@@ -2249,7 +2341,20 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 							Z.z0 = (uint4 *)fa->d_fr; Z.z1 = (uint4 *)fa->d_rf; Z.n0 = Z.n1 = (uint32_t)(lean_bits_bytes/16); Z.ctrl = d_counters;
 							cleared_bits = true;
 						}
-						if(ctx->s2_dbg)
+						if(use_seed3){
+							Seed3Tables T3; T3.seeds = Tg.seeds; T3.chunk_prefix = d_s3_prefix + g_prefix; T3.masks = Tg.masks; T3.floors = Tg.floors;
+							g_prefix += Tg.n_seeds + 1u;
+							T3.n_seeds = Tg.n_seeds; T3.n_or = Tg.n_or; T3.or_base = Tg.or_base;
+							T3.pix_first = S.pix_first.p; T3.pix_last = S.pix_last.p; T3.pix_pos = S.pix_pos.p; T3.pix_ctx = S.pix_ctx.p;
+							Seed3Set Q3 = { S.tb_d(), S.valid_d(), S.blk_seq.p, S.d_blk_off.p, S.d_active.p, S.tile_degen.p, S.seq_tile0.p };
+							const size_t dyn3 = (size_t)g_or*sizeof(uint4) + ((size_t)Tg.n_seeds + 1)*sizeof(uint32_t) + (((size_t)g_or + 15) & ~size_t(15)) + 16;
+							if(!ctx->s3_attr_set){
+								HIP_TRY(hipFuncSetAttribute((const void *)k_seed3, hipFuncAttributeMaxDynamicSharedMemorySize, 96*1024));
+								ctx->s3_attr_set = true;
+							}
+							hipLaunchKernelGGL(k_seed3, dim3(ctx->n_cu*4), dim3(S3_THREADS), dyn3, ctx->stream, T3, Q3, IA, ctx->d_cand_fwd, ctx->d_cand_floor, sink, Z);
+						}
+						else if(ctx->s2_dbg)
 							hipLaunchKernelGGL(k_seed2<true>, sgrid, sblock, dyn, ctx->stream, S.tb_d(), S.valid_d(), S.tile_desc.p, S.n_tiles, Tg, S.d_active.p, ctx->d_cand_fwd, ctx->d_cand_floor, ncand, IA, sink,
 							ctx->s2_dbg, Z);
 						else
