@@ -726,7 +726,7 @@ struct pcr_ctx {
 	struct S2Key { uint32_t a, c, g, t, floor_; bool operator==(const S2Key &o) const { return a == o.a && c == o.c && g == o.g && t == o.t && floor_ == o.floor_; } };
 	struct S2KeyHash { size_t operator()(const S2Key &k) const { uint64_t h = 0x9E3779B97F4A7C15ull; for(uint32_t v : {k.a, k.c, k.g, k.t, k.floor_}){ h ^= v; h *= 0x100000001B3ull; h ^= h >> 29; } return (size_t)h; } };
 	struct S2Entry { std::vector<uint32_t> seeds; /* code << 14 | off << 9 */ uint32_t off_mask; bool seedable;
-		std::vector<uint32_t> chunks; uint64_t chunks_gen = 0; /* third form: 64-entry chunks of the seeds' runs in the set whose position index has this generation */ };
+		std::vector<uint32_t> chunks; uint32_t chunks_total = 0; uint64_t chunks_gen = 0; /* third form: running 64-entry chunks of the seeds' runs in the set whose position index has this generation */ };
 	std::unordered_map<S2Key, S2Entry, S2KeyHash> s2_cache;
 	std::vector<pcrhost::Seed> s2_tmp;
 	std::vector<uint32_t> s3_prefix; bool no_seed3 = false, s3_attr_set = false;   // third form: the pass's chunk list; PCRAMP_SEED3=0: second form (A/B)
@@ -1796,8 +1796,15 @@ inline uint32_t spread16(uint32_t v) { uint32_t r = 0; for(int i = 0;i < 16;++i)
 // batch of 1 000 trial assays (pcramp.h:32) is 4 000 orientations = 16+ groups (r02 sent it to the first form with host-built
 // tables: 21 ms per select_words on a C5 shard).  false: an orientation whose seeds alone exceed one launch.
 constexpr uint32_t S2_MAX_GROUPS = 4096;
-bool plan_seed2(pcr_ctx *ctx, const std::vector<pcrhost::Candidate> &cand, std::vector<uint32_t> &or_seed, std::vector<uint32_t> &or_plain, uint32_t &irr_off_mask)
+// S3 (optional): the set whose position index the third form will read -- the chunk list of every launch group (ctx->s3_prefix: the
+// running number of 64-entry chunks of the group's seeds' runs, its total behind it) is made alongside, from chunk counts cached
+// beside each oligo's seeds for the set last used.
+bool plan_seed2(pcr_ctx *ctx, const std::vector<pcrhost::Candidate> &cand, std::vector<uint32_t> &or_seed, std::vector<uint32_t> &or_plain, uint32_t &irr_off_mask,
+	const SeqSet *S3 = nullptr)
 {
+	std::vector<uint32_t> &pf = ctx->s3_prefix;
+	pf.clear();
+	uint32_t pf_run = 0;
 	const uint32_t n_or = 2*(uint32_t)cand.size();
 	std::vector<uint32_t> &out = ctx->s2_seeds;
 	out.clear(); ctx->s2_group_end.clear(); ctx->s2_group_offmask.clear(); ctx->s2_group_or.clear(); ctx->s2_group_nor.clear();
@@ -1818,7 +1825,7 @@ bool plan_seed2(pcr_ctx *ctx, const std::vector<pcrhost::Candidate> &cand, std::
 			for(const pcrhost::Seed &sd : ctx->s2_tmp){ e.seeds.push_back((sd.code << 14) | ((uint32_t)sd.off << 9)); e.off_mask |= 1u << sd.off; }
 			it = ctx->s2_cache.emplace(key, std::move(e)).first;
 		}
-		const pcr_ctx::S2Entry &e = it->second;
+		pcr_ctx::S2Entry &e = it->second;
 		if(!e.seedable){ or_plain.push_back(o); continue; }
 		or_seed.push_back(o);
 		// the group spans orientations [group_or0, o]: unseedable ones in between only take an (unused) id
@@ -1826,15 +1833,29 @@ bool plan_seed2(pcr_ctx *ctx, const std::vector<pcrhost::Candidate> &cand, std::
 			if(!fits(e.seeds.size(), 1) || ctx->s2_group_end.size() + 1 >= S2_MAX_GROUPS) return false;
 			ctx->s2_group_end.push_back((uint32_t)out.size()); ctx->s2_group_offmask.push_back(group_mask); ctx->s2_group_or.push_back(group_or0); ctx->s2_group_nor.push_back(group_last - group_or0 + 1);
 			group_begin = out.size(); group_mask = 0; group_or0 = o;
+			if(S3){ pf.push_back(pf_run); pf_run = 0; }                                // the group's total; the next one starts at 0
 		}
 		group_last = o;
 		const size_t at = out.size();
 		out.resize(at + e.seeds.size());
 		for(size_t k = 0;k < e.seeds.size();++k) out[at + k] = e.seeds[k] | (o - group_or0);
+		if(S3){
+			if(e.chunks_gen != S3->pix_generation){                                   // exclusive running chunk counts of the oligo's seeds in this set
+				e.chunks.resize(e.seeds.size());
+				uint32_t run = 0;
+				for(size_t k = 0;k < e.seeds.size();++k){ e.chunks[k] = run; run += (S3->pix_count_h[e.seeds[k] >> 14] + 63u) >> 6; }
+				e.chunks_total = run; e.chunks_gen = S3->pix_generation;
+			}
+			const size_t pa = pf.size();
+			pf.resize(pa + e.chunks.size());
+			for(size_t k = 0;k < e.chunks.size();++k) pf[pa + k] = pf_run + e.chunks[k];
+			pf_run += e.chunks_total;
+		}
 		if(!(o & 1u)){ irr_off_mask |= e.off_mask; group_mask |= e.off_mask; }   // slot offsets at which forward seeds sit (irregular-word scan)
 	}
 	ctx->s2_group_end.push_back((uint32_t)out.size()); ctx->s2_group_offmask.push_back(group_mask); ctx->s2_group_or.push_back(group_or0);
 	ctx->s2_group_nor.push_back(or_seed.empty() ? 0u : group_last - group_or0 + 1);
+	if(S3) pf.push_back(pf_run);
 	return true;
 }
 
@@ -2085,9 +2106,22 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 	// The second form of the seed scan (pcr_scan_seed2.inc) takes the pass when no 5'/3' shift candidates are asked for and
 	// the orientations and their 9-gram seeds fit its LDS budget; the host then only LISTS the seeds (from a cache keyed by
 	// oligo and floor: between two optimiser iterations most oligos stay what they were).
+	bool want_seed3 = false;
+	if(ctx->scan_version == 3 && !ctx->force_seed1 && !optimize_5 && !optimize_3 && n_or <= 65535 && !ctx->no_seed3 && !ctx->no_irr_index && ctx->s2_dbg == 0){
+		int irc = ensure_pos_index(ctx, S);
+		if(irc != PCR_OK) return irc;
+		uint32_t n_live0 = 0;
+		for(uint32_t k = std::min<uint32_t>(min_oligo_length, 256);k < 256;++k) n_live0 += S.irr_size_count[k];
+		bool irr_ok = n_live0 == 0;
+		if(S.pix_usable && !irr_ok && S.irr_n_multi == 0 && (uint64_t)24*S.n_irr < (uint64_t(1) << 32)){
+			if((irc = ensure_irr_index(ctx, S)) != PCR_OK) return irc;
+			irr_ok = S.irx_usable;
+		}
+		want_seed3 = S.pix_usable && irr_ok;
+	}
 	bool use_seed2 = false;
 	if(ctx->scan_version == 3 && !ctx->force_seed1 && !optimize_5 && !optimize_3 && n_or <= 65535){
-		use_seed2 = plan_seed2(ctx, cand, or_seed, or_plain, irr_off_mask);
+		use_seed2 = plan_seed2(ctx, cand, or_seed, or_plain, irr_off_mask, want_seed3 ? &S : nullptr);
 		// an orientation without a 9-gram structure (low thresholds: k = 4 mismatching slots and more) may still have an 8-gram
 		// one: let the first form plan the pass where it can (it hands fewer orientations to the bit-sliced scan); a batch beyond
 		// its S1_MAX_OR orientations keeps this form for the seedable orientations, the others go to the bit-sliced scan
@@ -2095,47 +2129,9 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 		if(!use_seed2){ or_seed.clear(); or_plain.clear(); irr_off_mask = 0; }
 	}
 	// ... and the third form -- the targets' positions indexed by their 9-grams, the seeds looked up (pcr_scan_seed3.inc) -- where every
-	// candidate is seeded and the irregular words can come in through their index too
-	bool use_seed3 = false;
-	if(use_seed2 && or_plain.empty() && !or_seed.empty() && !ctx->no_seed3 && !ctx->no_irr_index && ctx->s2_dbg == 0){
-		int irc = ensure_pos_index(ctx, S);
-		if(irc != PCR_OK) return irc;
-		uint32_t n_live0 = 0;
-		for(uint32_t k = std::min<uint32_t>(min_oligo_length, 256);k < 256;++k) n_live0 += S.irr_size_count[k];
-		bool irr_ok = n_live0 == 0;
-		if(!irr_ok && S.irr_n_multi == 0 && (uint64_t)24*S.n_irr < (uint64_t(1) << 32)){
-			if((irc = ensure_irr_index(ctx, S)) != PCR_OK) return irc;
-			irr_ok = S.irx_usable;
-		}
-		use_seed3 = S.pix_usable && irr_ok;
-		if(use_seed3){
-			// the chunk list of every launch group: the running number of 64-entry chunks of its seeds' runs.  The seed list is the
-			// seeded orientations' cached lists one after the other (plan_seed2), so are the chunk counts, cached beside them per oligo
-			// for the set last used (a look-up of the run lengths per seed was 20 us of host time per pass)
-			std::vector<uint32_t> &pf = ctx->s3_prefix;
-			pf.clear();
-			size_t si = 0, g = 0;
-			uint64_t run = 0;
-			for(uint32_t o : or_seed){
-				const pcrhost::Candidate &c = cand[o >> 1];
-				const Planes &m = (o & 1u) ? c.rc : c.fwd;
-				const pcr_ctx::S2Key key = {m.a, m.c, m.g, m.t, c.floor_};
-				pcr_ctx::S2Entry &e = ctx->s2_cache.find(key)->second;               // (plan_seed2 has just put it there)
-				if(e.chunks_gen != S.pix_generation){
-					e.chunks.resize(e.seeds.size());
-					for(size_t k = 0;k < e.seeds.size();++k) e.chunks[k] = (S.pix_count_h[e.seeds[k] >> 14] + 63u) >> 6;
-					e.chunks_gen = S.pix_generation;
-				}
-				for(size_t k = 0;k < e.chunks.size();++k, ++si){
-					while(g < ctx->s2_group_end.size() && si == ctx->s2_group_end[g]){ pf.push_back((uint32_t)run); run = 0; ++g; }   // a group ends: its total, then the next one starts at 0
-					pf.push_back((uint32_t)run);
-					run += e.chunks[k];
-				}
-			}
-			pf.push_back((uint32_t)run);
-			if(si != ctx->s2_seeds.size() || pf.size() != ctx->s2_seeds.size() + ctx->s2_group_end.size()) use_seed3 = false;   // (the lists disagree: keep the second form)
-		}
-	}
+	// candidate is seeded (and the irregular words can come in through their index too: want_seed3, decided before the planning)
+	const bool use_seed3 = use_seed2 && want_seed3 && or_plain.empty() && !or_seed.empty()
+		&& ctx->s3_prefix.size() == ctx->s2_seeds.size() + ctx->s2_group_end.size();
 	bool dev_tables = false;                           // first form, tables built by k_seed_tables
 	if(!use_seed2 && ctx->scan_version == 3 && !ctx->host_seed_tables && !optimize_5 && !optimize_3 && n_or <= S1_MAX_OR){
 		plan_seed1(ctx, cand, or_seed, or_plain, irr_off_mask);
