@@ -762,8 +762,13 @@ def main():
         # which kernel is the scan: the second form of the seed filter at the reference's default thresholds; below that (select
         # threshold 0.81: 4-5 mismatching slots, ~160 seed codes per orientation) the first form with tables built on the device
         default_regime = select_thr >= 0.85
-        kname = "k_seed2" if default_regime else "k_seed"
-        klabel = ("k_seed2 (seed-filter oligo x window match scan, second form: 9-gram seeds, tables built in LDS)" if default_regime else
+        # the third form (k_seed3: the seeds looked up in the set's 9-gram position index) where it applies -- the default; PCRAMP_SEED3=0 or a
+        # set it cannot serve keeps the second form (k_seed2: a table probe per position)
+        third = default_regime and os.environ.get("PCRAMP_SEED3", "1") != "0" and os.environ.get("PCRAMP_IRR_INDEX", "1") != "0" and os.environ.get("PCRAMP_S2DBG", "0") in ("", "0")
+        kname = ("k_seed3" if third else "k_seed2") if default_regime else "k_seed"
+        klabel = (("k_seed3 (oligo x window match scan, third form: the pass's 9-gram seeds looked up in the targets' position index, every entry "
+                   "carrying the 64 bases around it)" if third else
+                   "k_seed2 (seed-filter oligo x window match scan, second form: 9-gram seeds, tables built in LDS)") if default_regime else
                   "k_seed<true> (seed-filter oligo x window match scan, first form: dense 8-gram tables built by k_seed_tables)")
         suffix = "" if default_regime else "_thr081"
         comparable = args.config == "C2" and args.scale == 1.0 and not args.random_primers and not args.optimize_shifts
@@ -828,7 +833,8 @@ def main():
                          "kernel": klabel,
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm_frac, "frac_once_per_pass": hbm_frac,
                          "note": "achieved = bytes one launch must read at least once (packed targets + oligos + result bits) / kernel time "
-                                 "(HIP events on the launch stream, every 4th pass); the kernel is bound by VALU issue, see valu",
+                                 "(HIP events on the launch stream, every 4th pass); k_seed3 does not read the targets at all but the runs of its seeds in "
+                                 "the position index (traffic), so `achieved` is an algorithmic rate, not the kernel's own memory traffic",
                          "algorithmic_bytes_per_launch": once,
                          "algorithmic_per_pair": {"bytes_per_launch": per_pair, "achieved": per_pair / kern_s / 1e9 if kern_s > 0 else None,
                                                   "frac": per_pair / kern_s / 1e9 / HBM_PEAK_GBPS if kern_s > 0 else None,
