@@ -646,7 +646,7 @@ struct SeqSet {
 	DevBuf<uint32_t> irx_first, irx_last, irx_words, irx_sums; bool irx_valid = false, irx_usable = false;   // their inverse index (pcr_scan_seed2.inc), built on demand; usable: no key's run is longer than IRX_MAX_RUN
 	uint32_t irr_n_multi = 0;     // irregular words holding an IUPAC slot (they meet every candidate: no index for them)
 	// the positions of the set by the 9-gram that starts there (pcr_scan_seed3.inc), built on demand after a load
-	DevBuf<uint32_t> pix_first, pix_last, pix_pos, pix_sums, seq_tile0; DevBuf<uint4> pix_ctx; std::vector<uint32_t> pix_count_h; uint64_t pix_generation = 0; bool pix_valid = false, pix_usable = false;
+	DevBuf<uint32_t> pix_first, pix_last, pix_pos, pix_sums, blk_info, blk_local; DevBuf<uint4> pix_ctx; std::vector<uint32_t> pix_count_h; uint64_t pix_generation = 0; bool pix_valid = false, pix_usable = false;
 	DevBuf<uint8_t> codes; DevBuf<uint64_t> d_code_off; bool have_codes = false;
 	// word DB of the last select
 	bool have_db = false;
@@ -661,7 +661,7 @@ struct SeqSet {
 	uint32_t *d_seg_hi = nullptr;
 	void release()
 	{
-		d_weight.release(); tile_desc.release(); irr_scan.release(); irx_first.release(); irx_last.release(); irx_words.release(); irx_sums.release(); pix_first.release(); pix_last.release(); pix_pos.release(); pix_ctx.release(); pix_sums.release(); seq_tile0.release(); irr_perm.release(); planes.release(); valid.release(); nib.release(); tb.release(); degen_tiles.release(); tile_degen.release(); blk_seq.release(); tile_seq.release(); tile_pos0.release();
+		d_weight.release(); tile_desc.release(); irr_scan.release(); irx_first.release(); irx_last.release(); irx_words.release(); irx_sums.release(); pix_first.release(); pix_last.release(); pix_pos.release(); pix_ctx.release(); pix_sums.release(); blk_info.release(); blk_local.release(); irr_perm.release(); planes.release(); valid.release(); nib.release(); tb.release(); degen_tiles.release(); tile_degen.release(); blk_seq.release(); tile_seq.release(); tile_pos0.release();
 		irr_off.release(); d_len.release(); d_blk_off.release();
 		d_nblk_real.release(); d_active.release(); d_has_eos.release(); irr.release(); db.release(); touched.release(); ctrl.release(); codes.release(); d_code_off.release();
 	}
@@ -984,6 +984,30 @@ int ensure_pos_index(pcr_ctx *ctx, SeqSet &S)
 	if((rc = S.pix_sums.ensure(n_blocks + 4)) != PCR_OK) return rc;
 	if((rc = S.pix_pos.ensure(S.total_blocks*32 + 64)) != PCR_OK) return rc;
 	if((rc = S.pix_ctx.ensure(S.total_blocks*32 + 64)) != PCR_OK) return rc;
+	{
+		// per 32-base block: its sequence (bit 31: the tile it lies in holds IUPAC codes) and its number within the sequence -- what a
+		// window that reached its floor is asked, in one round trip
+		if(S.n >= (1u << 31)){ return PCR_OK; }
+		if((rc = S.blk_info.ensure(S.total_blocks + 1)) != PCR_OK) return rc;
+		if((rc = S.blk_local.ensure(S.total_blocks + 1)) != PCR_OK) return rc;
+		std::vector<uint8_t> degen(S.n_tiles + 1, 0);
+		if(S.n_tiles) HIP_TRY(hipMemcpyAsync(degen.data(), S.tile_degen.p, S.n_tiles, hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(hipStreamSynchronize(ctx->stream));
+		std::vector<uint32_t> info(S.total_blocks), local(S.total_blocks);
+		uint64_t t0 = 0;
+		for(uint32_t q = 0;q < S.n;++q){
+			const uint64_t nt = (S.len[q] >= 32) ? (S.len[q] - 7 + TILE_POS - 1)/TILE_POS : 0;
+			for(uint64_t b = S.blk_off[q];b < S.blk_off[q + 1];++b){
+				const uint64_t bl = b - S.blk_off[q], tile = bl >> 5;                 // 1 024 window starts per tile = 32 blocks
+				info[b] = q | ((tile < nt && degen[t0 + tile]) ? 0x80000000u : 0u);
+				local[b] = (uint32_t)bl;
+			}
+			t0 += nt;
+		}
+		HIP_TRY(hipMemcpyAsync(S.blk_info.p, info.data(), S.total_blocks*sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+		HIP_TRY(hipMemcpyAsync(S.blk_local.p, local.data(), S.total_blocks*sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+		HIP_TRY(hipStreamSynchronize(ctx->stream));
+	}
 	HIP_TRY(hipMemsetAsync(S.pix_last.p, 0, (size_t)PIX_CODES*sizeof(uint32_t), ctx->stream));
 	const unsigned grid = (unsigned)((S.total_blocks + 255)/256);
 	hipLaunchKernelGGL(k_pix_build<false>, dim3(grid), dim3(256), 0, ctx->stream, S.tb_d(), S.blk_seq.p, S.d_blk_off.p, S.d_len.p, S.total_blocks, S.pix_last.p, (uint32_t *)nullptr, (uint4 *)nullptr);
@@ -1618,11 +1642,10 @@ static int load_sequences_impl(pcr_ctx *ctx, int which, const uint8_t *packed4, 
 	S.n_tiles = (uint32_t)n_tiles;
 
 	// host-side index pieces: block -> sequence map, tile list, irregular words
-	std::vector<uint32_t> blk_seq(total_blocks), tile_seq(n_tiles), tile_pos0(n_tiles), seq_tile0((size_t)n + 1, 0);
+	std::vector<uint32_t> blk_seq(total_blocks), tile_seq(n_tiles), tile_pos0(n_tiles);
 	uint64_t t = 0;
 	S.pix_valid = false; S.pix_usable = false;
 	for(uint32_t s = 0;s < n;++s){
-		seq_tile0[s] = (uint32_t)t;
 		for(uint64_t b = S.blk_off[s];b < S.blk_off[s + 1];++b) blk_seq[b] = s;
 		if(lengths[s] >= 32){
 			const uint64_t nt = (lengths[s] - 7 + TILE_POS - 1)/TILE_POS;
@@ -1662,8 +1685,6 @@ static int load_sequences_impl(pcr_ctx *ctx, int which, const uint8_t *packed4, 
 	}
 	H2D(d_byte_off.p, dev_byte_off.data(), n*sizeof(uint64_t));
 	H2D(S.blk_seq.p, blk_seq.data(), total_blocks*sizeof(uint32_t));
-	if((rc = S.seq_tile0.ensure((size_t)n + 1)) != PCR_OK) return fail(rc);
-	H2D(S.seq_tile0.p, seq_tile0.data(), ((size_t)n + 1)*sizeof(uint32_t));
 	H2D(S.tile_seq.p, tile_seq.data(), n_tiles*sizeof(uint32_t));
 	H2D(S.tile_pos0.p, tile_pos0.data(), n_tiles*sizeof(uint32_t));
 	H2D(S.d_len.p, S.len.data(), n*sizeof(uint64_t));
@@ -2342,7 +2363,7 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 							g_prefix += Tg.n_seeds + 1u;
 							T3.n_seeds = Tg.n_seeds; T3.n_or = Tg.n_or; T3.or_base = Tg.or_base;
 							T3.pix_first = S.pix_first.p; T3.pix_last = S.pix_last.p; T3.pix_pos = S.pix_pos.p; T3.pix_ctx = S.pix_ctx.p;
-							Seed3Set Q3 = { S.tb_d(), S.valid_d(), S.blk_seq.p, S.d_blk_off.p, S.d_active.p, S.tile_degen.p, S.seq_tile0.p };
+							Seed3Set Q3 = { S.valid_d(), S.blk_info.p, S.blk_local.p, S.d_active.p };
 							const size_t dyn3 = (size_t)g_or*sizeof(uint4) + ((size_t)Tg.n_seeds + 1)*sizeof(uint32_t) + (((size_t)g_or + 15) & ~size_t(15)) + 16;
 							if(!ctx->s3_attr_set){
 								HIP_TRY(hipFuncSetAttribute((const void *)k_seed3, hipFuncAttributeMaxDynamicSharedMemorySize, 96*1024));
