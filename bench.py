@@ -764,11 +764,11 @@ def main():
         default_regime = select_thr >= 0.85
         # the third form (k_seed3: the seeds looked up in the set's 9-gram position index) where it applies -- the default; PCRAMP_SEED3=0 or a
         # set it cannot serve keeps the second form (k_seed2: a table probe per position)
-        third = default_regime and os.environ.get("PCRAMP_SEED3", "1") != "0" and os.environ.get("PCRAMP_IRR_INDEX", "1") != "0" and os.environ.get("PCRAMP_S2DBG", "0") in ("", "0")
-        kname = ("k_seed3" if third else "k_seed2") if default_regime else "k_seed"
+        third = default_regime and not args.optimize_shifts and os.environ.get("PCRAMP_SEED3", "1") != "0" and os.environ.get("PCRAMP_IRR_INDEX", "1") != "0" and os.environ.get("PCRAMP_S2DBG", "0") in ("", "0")
+        kname = ("k_seed3" if third else "k_seed2") if (default_regime and not args.optimize_shifts) else "k_seed"
         klabel = (("k_seed3 (oligo x window match scan, third form: the pass's 9-gram seeds looked up in the targets' position index, every entry "
                    "carrying the 64 bases around it)" if third else
-                   "k_seed2 (seed-filter oligo x window match scan, second form: 9-gram seeds, tables built in LDS)") if default_regime else
+                   "k_seed2 (seed-filter oligo x window match scan, second form: 9-gram seeds, tables built in LDS)") if (default_regime and not args.optimize_shifts) else
                   "k_seed<true> (seed-filter oligo x window match scan, first form: dense 8-gram tables built by k_seed_tables)")
         suffix = "" if default_regime else "_thr081"
         comparable = args.config == "C2" and args.scale == 1.0 and not args.random_primers and not args.optimize_shifts
