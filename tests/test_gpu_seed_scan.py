@@ -279,6 +279,57 @@ def test_screen_device_equals_separate_calls(both, oracle):
         assert np.array_equal(got[1], w[1])
 
 
+def _screener_env(**env):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        return api.Screener(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("thr_t", [1.0, 0.95])
+def test_three_forms_of_the_seed_pass_agree(oracle, thr_t):
+    """The default pass (third form: position index), the scanning form (PCRAMP_SEED3=0: k_seed2 with the
+    inverse index of the irregular words) and the scanning form with the irregular words probed in chunks
+    (PCRAMP_IRR_INDEX=0) give the same word DB entry for entry, on the border case (primer sites at every
+    kind of tile border and at the sequence ends) and after EOS splits -- and all equal the oracle."""
+    import torch
+    rng = random.Random(4242)
+    seqs, pairs = _border_case(rng, oracle)
+    thr = float(np.float32(thr_t) * np.float32(0.9))
+    devs = [api.Screener(0), _screener_env(PCRAMP_SEED3=0), _screener_env(PCRAMP_IRR_INDEX=0)]
+    try:
+        want = _oracle_entries(oracle, seqs, pairs, thr_t, 0.9)
+        got = [_entries(d, seqs, pairs, thr) for d in devs]
+        assert len(want) > 0
+        for g in got:
+            assert g == want
+        # the fused pass (where the third form is the default) after two EOS splits: same bitsets from all three
+        outs = []
+        for d in devs:
+            d.split(len(seqs) - 1, 2500)
+            d.split(3, 1030)
+            words = int(d.bitset_words())
+            o = torch.full((2, len(pairs), words), -1, dtype=torch.int64, device="cuda:0")
+            for _ in range(3):      # the lean pass starts with the second consecutive fused pass
+                d.screen_device(pairs, thr, o[0].data_ptr(), o[1].data_ptr(), thr_t, thr_t, 80, 200, False)
+            d.synchronize()
+            torch.cuda.synchronize()
+            outs.append(o.cpu().numpy().copy())
+        assert np.array_equal(outs[0], outs[1])
+        assert np.array_equal(outs[0], outs[2])
+        e = [d.entries() for d in devs]
+        assert e[0] == e[1] == e[2] and len(e[0]) > 0
+    finally:
+        for d in devs:
+            d.close()
+
+
 def test_lean_passes_leave_a_consistent_state(oracle):
     """From the second fused pass over a set on, the pass is 'lean': no staging launch (tables written into device memory by the
     host, control block left clean by the previous pass's tail, result bitsets cleared by the scan).  Batches that hit different
