@@ -646,7 +646,7 @@ struct SeqSet {
 	DevBuf<uint32_t> irx_first, irx_last, irx_words, irx_sums; bool irx_valid = false, irx_usable = false;   // their inverse index (pcr_scan_seed2.inc), built on demand; usable: no key's run is longer than IRX_MAX_RUN
 	uint32_t irr_n_multi = 0;     // irregular words holding an IUPAC slot (they meet every candidate: no index for them)
 	// the positions of the set by the 9-gram that starts there (pcr_scan_seed3.inc), built on demand after a load
-	DevBuf<uint32_t> pix_first, pix_last, pix_pos, pix_sums, blk_info, blk_local; DevBuf<uint4> pix_ctx; std::vector<uint32_t> pix_count_h; uint64_t pix_generation = 0; bool pix_valid = false, pix_usable = false;
+	DevBuf<uint32_t> pix_first, pix_last, pix_sums, blk_info, blk_local; DevBuf<uint4> pix_ent; std::vector<uint32_t> pix_count_h; uint64_t pix_generation = 0; bool pix_valid = false, pix_usable = false;
 	DevBuf<uint8_t> codes; DevBuf<uint64_t> d_code_off; bool have_codes = false;
 	// word DB of the last select
 	bool have_db = false;
@@ -661,7 +661,7 @@ struct SeqSet {
 	uint32_t *d_seg_hi = nullptr;
 	void release()
 	{
-		d_weight.release(); tile_desc.release(); irr_scan.release(); irx_first.release(); irx_last.release(); irx_words.release(); irx_sums.release(); pix_first.release(); pix_last.release(); pix_pos.release(); pix_ctx.release(); pix_sums.release(); blk_info.release(); blk_local.release(); irr_perm.release(); planes.release(); valid.release(); nib.release(); tb.release(); degen_tiles.release(); tile_degen.release(); blk_seq.release(); tile_seq.release(); tile_pos0.release();
+		d_weight.release(); tile_desc.release(); irr_scan.release(); irx_first.release(); irx_last.release(); irx_words.release(); irx_sums.release(); pix_first.release(); pix_last.release(); pix_ent.release(); pix_sums.release(); blk_info.release(); blk_local.release(); irr_perm.release(); planes.release(); valid.release(); nib.release(); tb.release(); degen_tiles.release(); tile_degen.release(); blk_seq.release(); tile_seq.release(); tile_pos0.release();
 		irr_off.release(); d_len.release(); d_blk_off.release();
 		d_nblk_real.release(); d_active.release(); d_has_eos.release(); irr.release(); db.release(); touched.release(); ctrl.release(); codes.release(); d_code_off.release();
 	}
@@ -982,8 +982,7 @@ int ensure_pos_index(pcr_ctx *ctx, SeqSet &S)
 	if((rc = S.pix_last.ensure(PIX_CODES + 4)) != PCR_OK) return rc;
 	const uint32_t n_blocks = (PIX_CODES + 4095u)/4096u;
 	if((rc = S.pix_sums.ensure(n_blocks + 4)) != PCR_OK) return rc;
-	if((rc = S.pix_pos.ensure(S.total_blocks*32 + 64)) != PCR_OK) return rc;
-	if((rc = S.pix_ctx.ensure(S.total_blocks*32 + 64)) != PCR_OK) return rc;
+	if((rc = S.pix_ent.ensure(S.total_blocks*32 + 64)) != PCR_OK) return rc;
 	{
 		// per 32-base block: its sequence (bit 31: the tile it lies in holds IUPAC codes) and its number within the sequence -- what a
 		// window that reached its floor is asked, in one round trip
@@ -1010,11 +1009,11 @@ int ensure_pos_index(pcr_ctx *ctx, SeqSet &S)
 	}
 	HIP_TRY(hipMemsetAsync(S.pix_last.p, 0, (size_t)PIX_CODES*sizeof(uint32_t), ctx->stream));
 	const unsigned grid = (unsigned)((S.total_blocks + 255)/256);
-	hipLaunchKernelGGL(k_pix_build<false>, dim3(grid), dim3(256), 0, ctx->stream, S.tb_d(), S.blk_seq.p, S.d_blk_off.p, S.d_len.p, S.total_blocks, S.pix_last.p, (uint32_t *)nullptr, (uint4 *)nullptr);
+	hipLaunchKernelGGL(k_pix_build<false>, dim3(grid), dim3(256), 0, ctx->stream, S.tb_d(), S.blk_seq.p, S.d_blk_off.p, S.d_len.p, S.total_blocks, S.pix_last.p, (uint4 *)nullptr);
 	hipLaunchKernelGGL(k_scan_blocks, dim3(n_blocks), dim3(1024), 0, ctx->stream, S.pix_last.p, S.pix_first.p, PIX_CODES, S.pix_sums.p);
 	hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, ctx->stream, S.pix_sums.p, n_blocks);
 	hipLaunchKernelGGL(k_scan_add, dim3(n_blocks), dim3(1024), 0, ctx->stream, S.pix_first.p, S.pix_last.p, PIX_CODES, S.pix_sums.p);
-	hipLaunchKernelGGL(k_pix_build<true>, dim3(grid), dim3(256), 0, ctx->stream, S.tb_d(), S.blk_seq.p, S.d_blk_off.p, S.d_len.p, S.total_blocks, S.pix_last.p, S.pix_pos.p, S.pix_ctx.p);
+	hipLaunchKernelGGL(k_pix_build<true>, dim3(grid), dim3(256), 0, ctx->stream, S.tb_d(), S.blk_seq.p, S.d_blk_off.p, S.d_len.p, S.total_blocks, S.pix_last.p, S.pix_ent.p);
 	HIP_TRY(hipGetLastError());
 	{
 		std::vector<uint32_t> first(PIX_CODES), last(PIX_CODES);
@@ -2362,7 +2361,7 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 							Seed3Tables T3; T3.seeds = Tg.seeds; T3.chunk_prefix = d_s3_prefix + g_prefix; T3.masks = Tg.masks; T3.floors = Tg.floors;
 							g_prefix += Tg.n_seeds + 1u;
 							T3.n_seeds = Tg.n_seeds; T3.n_or = Tg.n_or; T3.or_base = Tg.or_base;
-							T3.pix_first = S.pix_first.p; T3.pix_last = S.pix_last.p; T3.pix_pos = S.pix_pos.p; T3.pix_ctx = S.pix_ctx.p;
+							T3.pix_first = S.pix_first.p; T3.pix_last = S.pix_last.p; T3.pix_ent = S.pix_ent.p;
 							Seed3Set Q3 = { S.valid_d(), S.blk_info.p, S.blk_local.p, S.d_active.p };
 							const size_t dyn3 = (size_t)g_or*sizeof(uint4) + ((size_t)Tg.n_seeds + 1)*sizeof(uint32_t) + (((size_t)g_or + 15) & ~size_t(15)) + 16;
 							if(!ctx->s3_attr_set){

@@ -1,6 +1,6 @@
 # soak of the lean fused pass (GPU box): many passes over rotating target sets and changing primer batches, the bits of every
-# 500th pass compared with the synchronous path on a second handle
-import sys, time
+# 500th pass compared with the synchronous path on a second handle that runs the bit-sliced scan (PCRAMP_SCAN=2)
+import os, sys, time
 sys.path.insert(0, '/root/repo')
 import numpy as np, torch
 from pcramp_amd import api, synth, words as W
@@ -9,7 +9,8 @@ sets = [synth.workload("C2", k, 0.2) for k in range(3)]          # 2 000 targets
 devs, refs = [], []
 for wl in sets:
     d = api.Screener(0); d.load_sequences(wl["packed"], wl["byte_offsets"], wl["lengths"]); devs.append(d)
-    r = api.Screener(0); r.load_sequences(wl["packed"], wl["byte_offsets"], wl["lengths"]); refs.append(r)
+    os.environ["PCRAMP_SCAN"] = "2"; r = api.Screener(0); os.environ.pop("PCRAMP_SCAN")     # the checker counts every window (bit-sliced scan), no seeds, no index
+    r.load_sequences(wl["packed"], wl["byte_offsets"], wl["lengths"]); refs.append(r)
 batches = [sets[k]["pairs"][i:i + 10] for k in range(3) for i in (0, 10, 20, 30, 40)]
 thr = float(np.float32(1.0) * np.float32(0.9))
 words = int(devs[0].bitset_words())
