@@ -725,7 +725,7 @@ struct pcr_ctx {
 	std::vector<uint32_t> s2_group_end, s2_group_offmask, s2_group_or, s2_group_nor;   // per group: end in the seed list, forward-seed slot offsets, first orientation, orientations spanned   // the seed list in groups of whole orientations, each within one launch's LDS budget
 	struct S2Key { uint32_t a, c, g, t, floor_; bool operator==(const S2Key &o) const { return a == o.a && c == o.c && g == o.g && t == o.t && floor_ == o.floor_; } };
 	struct S2KeyHash { size_t operator()(const S2Key &k) const { uint64_t h = 0x9E3779B97F4A7C15ull; for(uint32_t v : {k.a, k.c, k.g, k.t, k.floor_}){ h ^= v; h *= 0x100000001B3ull; h ^= h >> 29; } return (size_t)h; } };
-	struct S2Entry { std::vector<uint32_t> seeds; /* code << 14 | off << 9 */ uint32_t off_mask; bool seedable;
+	struct S2Entry { std::vector<uint32_t> seeds; /* code << 14 | off << 9 */ uint32_t off_mask; bool seedable; uint4 mask; /* the orientation's interleaved mask entry (k_seed2 / k_seed3) */
 		std::vector<uint32_t> chunks; uint32_t chunks_total = 0; uint64_t chunks_gen = 0; /* third form: running 64-entry chunks of the seeds' runs in the set whose position index has this generation */ };
 	std::unordered_map<S2Key, S2Entry, S2KeyHash> s2_cache;
 	std::vector<pcrhost::Seed> s2_tmp;
@@ -791,6 +791,7 @@ struct pcr_ctx {
 	const uint4 *d_cand_fwd = nullptr, *d_cand_rc = nullptr; const uint32_t *d_cand_floor = nullptr;
 	const OligoDev *d_oligos = nullptr;
 	// host-side phase timers (PCRAMP_TIMING=1: printed by pcr_destroy)
+	bool debug_log = false;                       // PCRAMP_DEBUG: plan / launch lines on stderr (read once: getenv walks the environment)
 	bool timing = false; double t_host[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint64_t n_timed = 0;
 	// profiling
 	bool prof = false; uint32_t prof_stride = 1, prof_pass = 0;   // events bracket the scan of every prof_stride-th pass
@@ -1470,6 +1471,7 @@ pcr_ctx *pcr_create(int device, void *hip_stream, const pcr_params *params)
 	else{ ctx->params.pack_max_degen = 256; ctx->params.pack_min_gc = 0.0f; ctx->params.pack_max_gc = 1.0f; }
 	{ hipDeviceProp_t prop; if(hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->n_cu = (uint32_t)prop.multiProcessorCount; }
 	if(const char *v = getenv("PCRAMP_TIMING")) ctx->timing = v[0] == '1';
+	ctx->debug_log = getenv("PCRAMP_DEBUG") != nullptr;
 	if(const char *v = getenv("PCRAMP_DEBUG_EPOCH")) ctx->debug_epoch = (uint32_t)strtoul(v, nullptr, 0);   // test hook: start the pass counter near its wrap
 	if(const char *v = getenv("PCRAMP_OPT_PM")) ctx->opt_pm_global = v[0] == 'g';
 	if(const char *v = getenv("PCRAMP_DEBUG_OPT_TASKS")){ unsigned a = 0, b = 0; if(sscanf(v, "%u,%u", &a, &b) >= 1){ ctx->opt_dbg_wg_tasks = a; ctx->opt_dbg_task_cap = b; } }
@@ -1807,7 +1809,12 @@ int pcr_split(pcr_ctx *ctx, pcr_set which, uint32_t seq, uint64_t pos)
 
 namespace {
 
-inline uint32_t spread16(uint32_t v) { uint32_t r = 0; for(int i = 0;i < 16;++i) r |= ((v >> i) & 1u) << (2*i); return r; }
+inline uint32_t spread16(uint32_t v)               // bit i of the low half -> bit 2i
+{
+	v &= 0xFFFFu;
+	v = (v | (v << 8)) & 0x00FF00FFu; v = (v | (v << 4)) & 0x0F0F0F0Fu;
+	v = (v | (v << 2)) & 0x33333333u; return (v | (v << 1)) & 0x55555555u;
+}
 
 // The seeds of a pass for the second form of the seed scan: per orientation from the cache (derived on a miss), listed as
 // code << 14 | slot offset << 9 | orientation WITHIN ITS GROUP, in groups of at most S2_MAX_OR whole orientations, each of which
@@ -1829,6 +1836,7 @@ bool plan_seed2(pcr_ctx *ctx, const std::vector<pcrhost::Candidate> &cand, std::
 	std::vector<uint32_t> &out = ctx->s2_seeds;
 	out.clear(); ctx->s2_group_end.clear(); ctx->s2_group_offmask.clear(); ctx->s2_group_or.clear(); ctx->s2_group_nor.clear();
 	irr_off_mask = 0;
+	ctx->s2_masks.resize(n_or);
 	if(ctx->s2_cache.size() > 16384) ctx->s2_cache.clear();
 	size_t group_begin = 0; uint32_t group_mask = 0, group_or0 = 0, group_last = 0;
 	auto fits = [&](size_t n, uint32_t g_or){ return g_or <= S2_MAX_OR && n <= S2_MAX_SEEDS && sizeof(S2Shared) + 17*(size_t)g_or + 8*n + 1024 <= 160*1024; };   // the tables of a launch must fit one CU's LDS
@@ -1841,11 +1849,17 @@ bool plan_seed2(pcr_ctx *ctx, const std::vector<pcrhost::Candidate> &cand, std::
 			pcr_ctx::S2Entry e; e.off_mask = 0;
 			ctx->s2_tmp.clear();
 			e.seedable = pcrhost::orientation_seeds(m, c.floor_, 0, ctx->s2_tmp, nullptr, S2_Q);
+			// per orientation ONE 16-byte mask entry: the four base-set planes, slots 0..15 spread to the even bits (slot k -> bit 2k) and
+			// slots 16..31 to the odd bits (slot 16 + k -> bit 2k + 1): both halves of a window are counted by one multiplexer pass
+			// (s2_count) from one LDS read
+			e.mask = make_uint4(spread16(m.a) | (spread16(m.a >> 16) << 1), spread16(m.c) | (spread16(m.c >> 16) << 1),
+			                    spread16(m.g) | (spread16(m.g >> 16) << 1), spread16(m.t) | (spread16(m.t >> 16) << 1));
 			e.seeds.reserve(ctx->s2_tmp.size());
 			for(const pcrhost::Seed &sd : ctx->s2_tmp){ e.seeds.push_back((sd.code << 14) | ((uint32_t)sd.off << 9)); e.off_mask |= 1u << sd.off; }
 			it = ctx->s2_cache.emplace(key, std::move(e)).first;
 		}
 		pcr_ctx::S2Entry &e = it->second;
+		ctx->s2_masks[o] = e.mask;
 		if(!e.seedable){ or_plain.push_back(o); continue; }
 		or_seed.push_back(o);
 		// the group spans orientations [group_or0, o]: unseedable ones in between only take an (unused) id
@@ -2169,7 +2183,7 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 	Seed2Tables ST2; memset(&ST2, 0, sizeof(ST2));
 	const uint32_t *d_s3_prefix = nullptr;
 	const size_t n_seeds = use_seed2 ? ctx->s2_seeds.size() : dev_tables ? ctx->s1_seeds.size() : H.seeds.size() + H.n_inherited;
-	if(getenv("PCRAMP_DEBUG")) fprintf(stderr, "[pcramp] scan plan: %u candidates, %zu seeded orientations (%zu seeds), %zu plain, %u/%u IUPAC tiles, %u-slot buckets\n",
+	if(ctx->debug_log) fprintf(stderr, "[pcramp] scan plan: %u candidates, %zu seeded orientations (%zu seeds), %zu plain, %u/%u IUPAC tiles, %u-slot buckets\n",
 		ncand, or_seed.size(), n_seeds, or_plain.size(), S.n_degen_tiles, S.n_tiles, S.bucket_cap);
 	Scan2Tables tab_plain, tab_seedset;               // bit-sliced tables: unseedable orientations (all tiles) / seedable ones (IUPAC tiles)
 	const bool need_plain = (ctx->scan_version != 1) && !or_plain.empty();
@@ -2185,16 +2199,9 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 		bytes += (H.image.size() + H.heads.size() + H.multi.size() + 64)*sizeof(uint32_t);
 		std::vector<uint4> &masks2 = ctx->s2_masks; std::vector<uint8_t> &floors2 = ctx->s2_floors;
 		if(use_seed2){
-			// per orientation ONE 16-byte entry: the four base-set planes, slots 0..15 spread to the even bits (slot k -> bit 2k) and
-			// slots 16..31 to the odd bits (slot 16 + k -> bit 2k + 1): both halves of a window are counted by one multiplexer pass
-			// (s2_count) from one LDS read
-			masks2.resize((size_t)n_or); floors2.assign(((size_t)n_or + 15) & ~size_t(15), 0);
-			for(uint32_t o = 0;o < n_or;++o){
-				const Planes &m = (o & 1u) ? cand[o >> 1].rc : cand[o >> 1].fwd;
-				masks2[o] = make_uint4(spread16(m.a) | (spread16(m.a >> 16) << 1), spread16(m.c) | (spread16(m.c >> 16) << 1),
-				                       spread16(m.g) | (spread16(m.g >> 16) << 1), spread16(m.t) | (spread16(m.t >> 16) << 1));
-				floors2[o] = (uint8_t)std::min<uint32_t>(cand[o >> 1].floor_, 255u);
-			}
+			// (the mask entries come out of the per-oligo cache: plan_seed2)
+			floors2.assign(((size_t)n_or + 15) & ~size_t(15), 0);
+			for(uint32_t o = 0;o < n_or;++o) floors2[o] = (uint8_t)std::min<uint32_t>(cand[o >> 1].floor_, 255u);
 			bytes += masks2.size()*sizeof(uint4) + floors2.size() + ctx->s2_seeds.size()*sizeof(uint32_t) + 512;
 			if(use_seed3) bytes += ctx->s3_prefix.size()*sizeof(uint32_t) + 64;
 		}
@@ -2219,7 +2226,7 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 				&& S.bucket_cap == POST_CAP && 2*fa->n_pairs <= 32*POST_MASK_WORDS;
 			lean_bits_bytes = bits_bytes;
 		}
-		if(getenv("PCRAMP_DEBUG")) fprintf(stderr, "[pcramp] staging: %s\n", lean ? "lean (tables written into device memory, no staging launch)" : "k_stage");
+		if(ctx->debug_log) fprintf(stderr, "[pcramp] staging: %s\n", lean ? "lean (tables written into device memory, no staging launch)" : "k_stage");
 		Stager st(ctx);
 		if((rc = lean ? st.begin_direct(bytes) : st.begin(bytes)) != PCR_OK) return rc;
 		ctx->d_cand_fwd = st.put(hf.data(), ncand);
@@ -2350,7 +2357,7 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 						else if(irr_by_index){                                               // every candidate seeded, no IUPAC word in the set: the words come in through the index, by seed
 							IA.ix_first = S.irx_first.p; IA.ix_last = S.irx_last.p; IA.ix_words = S.irx_words.p; IA.n_live = 0;
 						}
-						if(getenv("PCRAMP_DEBUG")) fprintf(stderr, "[pcramp] k_seed2: %u workgroups, %u seeds of orientations %u..%u (group %zu of %zu), %zu + %zu B of LDS\n", sgrid.x, Tg.n_seeds,
+						if(ctx->debug_log) fprintf(stderr, "[pcramp] k_seed2: %u workgroups, %u seeds of orientations %u..%u (group %zu of %zu), %zu + %zu B of LDS\n", sgrid.x, Tg.n_seeds,
 							or0, or0 + g_or - 1, g + 1, ctx->s2_group_end.size(), sizeof(S2Shared), dyn);
 						S2Clear Z = { nullptr, 0u, nullptr, 0u, nullptr };
 						if(lean && !cleared_bits){                                           // the first launch of a lean pass clears the result bitsets
@@ -2406,7 +2413,7 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 					const uint32_t irr_wgs = (n_live + IRR_THREADS*IRR_PER_LANE - 1)/(IRR_THREADS*IRR_PER_LANE);
 					const dim3 fgrid(sgrid.x + irr_wgs);
 					irr_fused = true;
-					if(getenv("PCRAMP_DEBUG")) fprintf(stderr, "[pcramp] k_seed: %d workgroups per CU x %u CUs\n", per_cu, ctx->n_cu);
+					if(ctx->debug_log) fprintf(stderr, "[pcramp] k_seed: %d workgroups per CU x %u CUs\n", per_cu, ctx->n_cu);
 #define SEED_ARGS S.tb_d(), S.planes.p, S.valid_d(), S.d_blk_off.p, S.d_nblk_real.p, S.d_len.p, S.d_active.p, S.tile_seq.p, S.tile_pos0.p, \
 	S.tile_degen.p, S.n_tiles, ST, ctx->d_cand_fwd, ctx->d_cand_rc, ctx->d_cand_floor, ncand, IA, sgrid.x, sink
 					if(cand_lds) hipLaunchKernelGGL(k_seed<true>, fgrid, sblock, dyn, ctx->stream, SEED_ARGS);
@@ -2493,7 +2500,7 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 		while(want < h_counters[2] && want < MAX_BUCKET_CAP_GLOBAL) want *= 2;
 		S.bucket_cap = want;
 	}
-	if(getenv("PCRAMP_DEBUG")) fprintf(stderr, "[pcramp] pass done: %u-slot buckets, largest fill %u, %u sequences with entries\n", S.db_cap, h_counters[2], h_counters[3]);
+	if(ctx->debug_log) fprintf(stderr, "[pcramp] pass done: %u-slot buckets, largest fill %u, %u sequences with entries\n", S.db_cap, h_counters[2], h_counters[3]);
 	S.n_touched = h_counters[3];
 	S.n_entries = S.n_touched ? 1 : 0;   // "non-empty" marker; the exact count is taken on demand (count_entries)
 	S.have_db = true;

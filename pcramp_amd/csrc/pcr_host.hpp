@@ -47,16 +47,29 @@ inline void word_set(uint64_t w[2], int k, unsigned v)
 	w[k >> 4] = (w[k >> 4] & ~(uint64_t(0xF) << sh)) | (uint64_t(v) << sh);
 }
 
+// Bits 0, 4, 8, ... 60 of x gathered into bits 0 ... 15.
+inline uint32_t gather_every_4th(uint64_t x)
+{
+	x &= 0x1111111111111111ull;
+	x = (x | (x >> 3)) & 0x0303030303030303ull;
+	x = (x | (x >> 6)) & 0x000F000F000F000Full;
+	x = (x | (x >> 12)) & 0x000000FF000000FFull;
+	return (uint32_t)((x | (x >> 24)) & 0xFFFFu);
+}
+
 inline Planes planes_of_word(const uint64_t w[2])
 {
-	Planes p = {0, 0, 0, 0};
-	for(int k = 0;k < 32;++k){
-		const unsigned v = word_get(w, k);
-		p.a |= uint32_t(v & 1) << k;
-		p.c |= uint32_t((v >> 1) & 1) << k;
-		p.g |= uint32_t((v >> 2) & 1) << k;
-		p.t |= uint32_t((v >> 3) & 1) << k;
+	// slot k of a block is nibble 15 - (k & 15) (word_get): reverse the nibbles once, then plane j = every 4th bit from bit j
+	uint64_t r[2];
+	for(int h = 0;h < 2;++h){
+		const uint64_t b = __builtin_bswap64(w[h]);
+		r[h] = ((b >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((b & 0x0F0F0F0F0F0F0F0Full) << 4);
 	}
+	Planes p;
+	p.a = gather_every_4th(r[0]) | (gather_every_4th(r[1]) << 16);
+	p.c = gather_every_4th(r[0] >> 1) | (gather_every_4th(r[1] >> 1) << 16);
+	p.g = gather_every_4th(r[0] >> 2) | (gather_every_4th(r[1] >> 2) << 16);
+	p.t = gather_every_4th(r[0] >> 3) | (gather_every_4th(r[1] >> 3) << 16);
 	return p;
 }
 
