@@ -2371,11 +2371,15 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 							T3.pix_first = S.pix_first.p; T3.pix_last = S.pix_last.p; T3.pix_ent = S.pix_ent.p;
 							Seed3Set Q3 = { S.valid_d(), S.blk_info.p, S.blk_local.p, S.d_active.p };
 							const size_t dyn3 = (size_t)g_or*sizeof(uint4) + ((size_t)Tg.n_seeds + 1)*sizeof(uint32_t) + (((size_t)g_or + 15) & ~size_t(15)) + 16;
+							static const int s3_wg = getenv("PCRAMP_S3_WG") ? atoi(getenv("PCRAMP_S3_WG")) : 1024;       // A/B: workgroup size
+							static const int s3_per_cu = getenv("PCRAMP_S3_PER_CU") ? atoi(getenv("PCRAMP_S3_PER_CU")) : 0;
 							if(!ctx->s3_attr_set){
-								HIP_TRY(hipFuncSetAttribute((const void *)k_seed3, hipFuncAttributeMaxDynamicSharedMemorySize, 96*1024));
+								HIP_TRY(hipFuncSetAttribute((const void *)k_seed3<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 128*1024));
+								HIP_TRY(hipFuncSetAttribute((const void *)k_seed3<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 128*1024));
 								ctx->s3_attr_set = true;
 							}
-							hipLaunchKernelGGL(k_seed3, dim3(ctx->n_cu*4), dim3(S3_THREADS), dyn3, ctx->stream, T3, Q3, IA, ctx->d_cand_fwd, ctx->d_cand_floor, sink, Z);
+							if(s3_wg == 1024) hipLaunchKernelGGL(k_seed3<1024>, dim3(ctx->n_cu*(s3_per_cu ? s3_per_cu : 2)), dim3(1024), dyn3, ctx->stream, T3, Q3, IA, ctx->d_cand_fwd, ctx->d_cand_floor, sink, Z);
+							else hipLaunchKernelGGL(k_seed3<512>, dim3(ctx->n_cu*(s3_per_cu ? s3_per_cu : 4)), dim3(512), dyn3, ctx->stream, T3, Q3, IA, ctx->d_cand_fwd, ctx->d_cand_floor, sink, Z);
 						}
 						else if(ctx->s2_dbg)
 							hipLaunchKernelGGL(k_seed2<true>, sgrid, sblock, dyn, ctx->stream, S.tb_d(), S.valid_d(), S.tile_desc.p, S.n_tiles, Tg, S.d_active.p, ctx->d_cand_fwd, ctx->d_cand_floor, ncand, IA, sink,
