@@ -2366,20 +2366,36 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 						}
 						if(use_seed3){
 							Seed3Tables T3; T3.seeds = Tg.seeds; T3.chunk_prefix = d_s3_prefix + g_prefix; T3.masks = Tg.masks; T3.floors = Tg.floors;
+							const uint32_t *P = ctx->s3_prefix.data() + g_prefix;              // the group's chunk list, [n_seeds + 1]
 							g_prefix += Tg.n_seeds + 1u;
 							T3.n_seeds = Tg.n_seeds; T3.n_or = Tg.n_or; T3.or_base = Tg.or_base;
 							T3.pix_first = S.pix_first.p; T3.pix_last = S.pix_last.p; T3.pix_ent = S.pix_ent.p;
 							Seed3Set Q3 = { S.valid_d(), S.blk_info.p, S.blk_local.p, S.d_active.p };
-							const size_t dyn3 = (size_t)g_or*sizeof(uint4) + ((size_t)Tg.n_seeds + 1)*sizeof(uint32_t) + (((size_t)g_or + 15) & ~size_t(15)) + 16;
 							static const int s3_wg = getenv("PCRAMP_S3_WG") ? atoi(getenv("PCRAMP_S3_WG")) : 1024;       // A/B: workgroup size
 							static const int s3_per_cu = getenv("PCRAMP_S3_PER_CU") ? atoi(getenv("PCRAMP_S3_PER_CU")) : 0;
+							const uint32_t G = std::min<uint32_t>(ctx->n_cu*(uint32_t)(s3_per_cu ? s3_per_cu : (s3_wg == 1024 ? 2 : 4)), S3_MAX_WG);
+							// the chunks dealt to the workgroups in equal contiguous shares; per workgroup the first seed of its share (a merge walk)
+							Seed3Slices W3; memset(&W3, 0, sizeof(W3));
+							T3.n_chunks = P[Tg.n_seeds]; T3.per_wg = std::max<uint32_t>(1u, (T3.n_chunks + G - 1u)/G);
+							{
+								uint32_t at = 0;
+								for(uint32_t w = 0;w <= G;++w){
+									const uint64_t target = (uint64_t)w*T3.per_wg;
+									while(at + 1u < Tg.n_seeds && P[at + 1u] <= target) ++at;
+									W3.start[w] = at;
+								}
+								uint32_t cap = 2;
+								for(uint32_t w = 0;w < G;++w) cap = std::max(cap, std::min(W3.start[w + 1] + 2u, Tg.n_seeds + 1u) - W3.start[w]);
+								T3.slice_cap = cap;
+							}
+							const size_t dyn3 = (size_t)g_or*sizeof(uint4) + 2*(size_t)T3.slice_cap*sizeof(uint32_t) + (((size_t)g_or + 15) & ~size_t(15)) + 16;
 							if(!ctx->s3_attr_set){
 								HIP_TRY(hipFuncSetAttribute((const void *)k_seed3<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 128*1024));
 								HIP_TRY(hipFuncSetAttribute((const void *)k_seed3<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 128*1024));
 								ctx->s3_attr_set = true;
 							}
-							if(s3_wg == 1024) hipLaunchKernelGGL(k_seed3<1024>, dim3(ctx->n_cu*(s3_per_cu ? s3_per_cu : 2)), dim3(1024), dyn3, ctx->stream, T3, Q3, IA, ctx->d_cand_fwd, ctx->d_cand_floor, sink, Z);
-							else hipLaunchKernelGGL(k_seed3<512>, dim3(ctx->n_cu*(s3_per_cu ? s3_per_cu : 4)), dim3(512), dyn3, ctx->stream, T3, Q3, IA, ctx->d_cand_fwd, ctx->d_cand_floor, sink, Z);
+							if(s3_wg == 1024) hipLaunchKernelGGL(k_seed3<1024>, dim3(G), dim3(1024), dyn3, ctx->stream, T3, Q3, IA, ctx->d_cand_fwd, ctx->d_cand_floor, sink, Z, W3);
+							else hipLaunchKernelGGL(k_seed3<512>, dim3(G), dim3(512), dyn3, ctx->stream, T3, Q3, IA, ctx->d_cand_fwd, ctx->d_cand_floor, sink, Z, W3);
 						}
 						else if(ctx->s2_dbg)
 							hipLaunchKernelGGL(k_seed2<true>, sgrid, sblock, dyn, ctx->stream, S.tb_d(), S.valid_d(), S.tile_desc.p, S.n_tiles, Tg, S.d_active.p, ctx->d_cand_fwd, ctx->d_cand_floor, ncand, IA, sink,
