@@ -729,6 +729,8 @@ struct pcr_ctx {
 		std::vector<uint32_t> chunks; uint32_t chunks_total = 0; uint64_t chunks_gen = 0; /* third form: running 64-entry chunks of the seeds' runs in the set whose position index has this generation */ };
 	std::unordered_map<S2Key, S2Entry, S2KeyHash> s2_cache;
 	std::vector<pcrhost::Seed> s2_tmp;
+	struct S3Launch { Seed3Slices W; uint32_t n_chunks, per_wg, slice_cap; };
+	std::vector<S3Launch> s3_launch;               // third form: per launch group, the workgroups' slices of the chunk list
 	std::vector<uint32_t> s3_prefix; bool no_seed3 = false, s3_attr_set = false;   // third form: the pass's chunk list; PCRAMP_SEED3=0: second form (A/B)
 	bool s2_attr_set = false; uint32_t s2_dbg = 0; bool no_irr_index = false;   // PCRAMP_IRR_INDEX=0: the irregular words scanned in chunks by every wave (A/B)
 	// first form, tables built on the device (k_seed_tables): the pass's seed list, its own per-oligo cache (8-gram seeds), the tables
@@ -1839,7 +1841,12 @@ bool plan_seed2(pcr_ctx *ctx, const std::vector<pcrhost::Candidate> &cand, std::
 	ctx->s2_masks.resize(n_or);
 	if(ctx->s2_cache.size() > 16384) ctx->s2_cache.clear();
 	size_t group_begin = 0; uint32_t group_mask = 0, group_or0 = 0, group_last = 0;
-	auto fits = [&](size_t n, uint32_t g_or){ return g_or <= S2_MAX_OR && n <= S2_MAX_SEEDS && sizeof(S2Shared) + 17*(size_t)g_or + 8*n + 1024 <= 160*1024; };   // the tables of a launch must fit one CU's LDS
+	// the tables of a launch must fit one CU's LDS; the third form keeps only the masks and a slice of the lists there: more orientations
+	// (9-bit ids) and as many seeds as the pass has -- plan_seed3_slices() checks its LDS need afterwards
+	auto fits = [&](size_t n, uint32_t g_or){
+		if(S3) return g_or <= S3_MAX_OR && n <= S3_MAX_SEEDS;
+		return g_or <= S2_MAX_OR && n <= S2_MAX_SEEDS && sizeof(S2Shared) + 17*(size_t)g_or + 8*n + 1024 <= 160*1024;
+	};
 	for(uint32_t o = 0;o < n_or;++o){
 		const pcrhost::Candidate &c = cand[o >> 1];
 		const Planes &m = (o & 1u) ? c.rc : c.fwd;
@@ -1890,6 +1897,43 @@ bool plan_seed2(pcr_ctx *ctx, const std::vector<pcrhost::Candidate> &cand, std::
 	ctx->s2_group_end.push_back((uint32_t)out.size()); ctx->s2_group_offmask.push_back(group_mask); ctx->s2_group_or.push_back(group_or0);
 	ctx->s2_group_nor.push_back(or_seed.empty() ? 0u : group_last - group_or0 + 1);
 	if(S3) pf.push_back(pf_run);
+	return true;
+}
+
+// Third form: the chunks of every launch group dealt to G workgroups in equal contiguous shares, and per workgroup the first seed of its
+// share (a merge walk over the group's chunk list).  false: some group's largest slice does not fit the LDS (many seeds whose runs are
+// empty side by side: tiny target sets) -- the caller plans again within the second form's limits.
+constexpr size_t S3_LDS_BUDGET = 120*1024;
+uint32_t seed3_grid(const pcr_ctx *ctx, int *wg_threads)
+{
+	static const int s3_wg = getenv("PCRAMP_S3_WG") ? atoi(getenv("PCRAMP_S3_WG")) : 1024;       // A/B: workgroup size, workgroups per CU
+	static const int s3_per_cu = getenv("PCRAMP_S3_PER_CU") ? atoi(getenv("PCRAMP_S3_PER_CU")) : 0;
+	if(wg_threads) *wg_threads = (s3_wg == 1024) ? 1024 : 512;
+	return std::min<uint32_t>(ctx->n_cu*(uint32_t)(s3_per_cu ? s3_per_cu : (s3_wg == 1024 ? 2 : 4)), S3_MAX_WG);
+}
+bool plan_seed3_slices(pcr_ctx *ctx)
+{
+	const uint32_t G = seed3_grid(ctx, nullptr);
+	ctx->s3_launch.resize(ctx->s2_group_end.size());
+	size_t g_begin = 0, g_prefix = 0;
+	for(size_t g = 0;g < ctx->s2_group_end.size();++g){
+		const uint32_t ns = ctx->s2_group_end[g] - (uint32_t)g_begin;
+		g_begin = ctx->s2_group_end[g];
+		const uint32_t *P = ctx->s3_prefix.data() + g_prefix;                  // the group's chunk list, [ns + 1]
+		g_prefix += (size_t)ns + 1;
+		pcr_ctx::S3Launch &L = ctx->s3_launch[g];
+		L.n_chunks = P[ns]; L.per_wg = std::max<uint32_t>(1u, (L.n_chunks + G - 1u)/G); L.slice_cap = 2;
+		if(ns == 0) continue;
+		uint32_t at = 0;
+		for(uint32_t w = 0;w <= G;++w){
+			const uint64_t target = (uint64_t)w*L.per_wg;
+			while(at + 1u < ns && P[at + 1u] <= target) ++at;
+			L.W.start[w] = at;
+		}
+		for(uint32_t w = G + 1;w <= S3_MAX_WG;++w) L.W.start[w] = at;
+		for(uint32_t w = 0;w < G;++w) L.slice_cap = std::max(L.slice_cap, std::min(L.W.start[w + 1] + 2u, ns + 1u) - L.W.start[w]);
+		if(17*(size_t)ctx->s2_group_nor[g] + 8*(size_t)L.slice_cap + 64 > S3_LDS_BUDGET) return false;
+	}
 	return true;
 }
 
@@ -2156,6 +2200,11 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 	bool use_seed2 = false;
 	if(ctx->scan_version == 3 && !ctx->force_seed1 && !optimize_5 && !optimize_3 && n_or <= 65535){
 		use_seed2 = plan_seed2(ctx, cand, or_seed, or_plain, irr_off_mask, want_seed3 ? &S : nullptr);
+		if(want_seed3 && !(use_seed2 && or_plain.empty() && !or_seed.empty() && plan_seed3_slices(ctx))){
+			// the third form will not take the pass (an unseeded candidate, or its lists do not fit): plan within the second form's limits
+			or_seed.clear(); or_plain.clear();
+			use_seed2 = plan_seed2(ctx, cand, or_seed, or_plain, irr_off_mask, nullptr);
+		}
 		// an orientation without a 9-gram structure (low thresholds: k = 4 mismatching slots and more) may still have an 8-gram
 		// one: let the first form plan the pass where it can (it hands fewer orientations to the bit-sliced scan); a batch beyond
 		// its S1_MAX_OR orientations keeps this form for the seedable orientations, the others go to the bit-sliced scan
@@ -2366,28 +2415,15 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 						}
 						if(use_seed3){
 							Seed3Tables T3; T3.seeds = Tg.seeds; T3.chunk_prefix = d_s3_prefix + g_prefix; T3.masks = Tg.masks; T3.floors = Tg.floors;
-							const uint32_t *P = ctx->s3_prefix.data() + g_prefix;              // the group's chunk list, [n_seeds + 1]
 							g_prefix += Tg.n_seeds + 1u;
 							T3.n_seeds = Tg.n_seeds; T3.n_or = Tg.n_or; T3.or_base = Tg.or_base;
 							T3.pix_first = S.pix_first.p; T3.pix_last = S.pix_last.p; T3.pix_ent = S.pix_ent.p;
 							Seed3Set Q3 = { S.valid_d(), S.blk_info.p, S.blk_local.p, S.d_active.p };
-							static const int s3_wg = getenv("PCRAMP_S3_WG") ? atoi(getenv("PCRAMP_S3_WG")) : 1024;       // A/B: workgroup size
-							static const int s3_per_cu = getenv("PCRAMP_S3_PER_CU") ? atoi(getenv("PCRAMP_S3_PER_CU")) : 0;
-							const uint32_t G = std::min<uint32_t>(ctx->n_cu*(uint32_t)(s3_per_cu ? s3_per_cu : (s3_wg == 1024 ? 2 : 4)), S3_MAX_WG);
-							// the chunks dealt to the workgroups in equal contiguous shares; per workgroup the first seed of its share (a merge walk)
-							Seed3Slices W3; memset(&W3, 0, sizeof(W3));
-							T3.n_chunks = P[Tg.n_seeds]; T3.per_wg = std::max<uint32_t>(1u, (T3.n_chunks + G - 1u)/G);
-							{
-								uint32_t at = 0;
-								for(uint32_t w = 0;w <= G;++w){
-									const uint64_t target = (uint64_t)w*T3.per_wg;
-									while(at + 1u < Tg.n_seeds && P[at + 1u] <= target) ++at;
-									W3.start[w] = at;
-								}
-								uint32_t cap = 2;
-								for(uint32_t w = 0;w < G;++w) cap = std::max(cap, std::min(W3.start[w + 1] + 2u, Tg.n_seeds + 1u) - W3.start[w]);
-								T3.slice_cap = cap;
-							}
+							int s3_wg = 0;
+							const uint32_t G = seed3_grid(ctx, &s3_wg);
+							const pcr_ctx::S3Launch &L3 = ctx->s3_launch[g];                   // (plan_seed3_slices)
+							T3.n_chunks = L3.n_chunks; T3.per_wg = L3.per_wg; T3.slice_cap = L3.slice_cap;
+							const Seed3Slices &W3 = L3.W;
 							const size_t dyn3 = (size_t)g_or*sizeof(uint4) + 2*(size_t)T3.slice_cap*sizeof(uint32_t) + (((size_t)g_or + 15) & ~size_t(15)) + 16;
 							if(!ctx->s3_attr_set){
 								HIP_TRY(hipFuncSetAttribute((const void *)k_seed3<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 128*1024));
