@@ -528,6 +528,25 @@ class Screener:
                                              select_threshold, min_oligo_length, C.byref(args),
                                              C.c_void_p(d_fr_ptr), C.c_void_p(d_rf_ptr)))
 
+    def screen_call(self, pairs, select_threshold, d_fr_ptr, d_rf_ptr, collect_threshold, ident_threshold,
+                    amp_min=80, amp_max=200, use_taq_mama=False, min_oligo_length=18, optimize_5=False,
+                    optimize_3=False, which=TARGET):
+        """screen_device() with its arguments converted once: returns a function of no arguments that enqueues the
+        pass.  For loops that issue the same call again and again from Python (bench.py): the ctypes conversions of
+        one call cost about as much host time as the library needs to plan a pass; a C or C++ caller has no such cost."""
+        a = np.ascontiguousarray(pairs if isinstance(pairs, np.ndarray) else W.pairs_array(pairs))
+        args = AmplifyArgs(collect_threshold, ident_threshold, amp_min, amp_max, int(use_taq_mama))
+        fn, check = self.L.pcr_screen_device, self._check
+        cargs = (C.c_void_p(self.h if isinstance(self.h, int) else self.h.value), C.c_int(which), C.c_void_p(a.ctypes.data), C.c_uint32(a.shape[0]),
+                 C.c_int(int(optimize_5)), C.c_int(int(optimize_3)), C.c_float(select_threshold), C.c_uint32(min_oligo_length),
+                 C.byref(args), C.c_void_p(d_fr_ptr), C.c_void_p(d_rf_ptr))
+
+        def call(_keep=(a, args)):
+            rc = fn(*cargs)
+            if rc:
+                check(rc)
+        return call
+
     def move_coverage(self, base_pair, side, variants, target_threshold=1.0, search_multiplier=0.9, amp_min=80, amp_max=200,
                       use_taq_mama=False, which=TARGET, bits=True):
         """optimize_pcr.cpp move evaluation: every variant of one oligo (side 0 = F, 1 = R) over the base pair's
