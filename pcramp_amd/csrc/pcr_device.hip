@@ -2496,7 +2496,10 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 	fa->d_oligos, fa->n_pairs, (2*fa->n_pairs + 31)/32, S.d_len.p, S.d_active.p, fa->a->amp_min, fa->a->amp_max, \
 	fa->a->ident_threshold, fa->a->use_taq_mama, fa->d_fr, fa->d_rf, bw, ctx->mail_dev + (ctx->mail_seq % pcr_ctx::MAIL_RING), ctx->mail_seq
 			if(cap == POST_CAP){
-				hipLaunchKernelGGL(k_post, dim3((S.n + POST_WAVES - 1)/POST_WAVES), dim3(64*POST_WAVES), 0, ctx->stream, POST_ARGS);
+				static const int post_waves = getenv("PCRAMP_POST_WAVES") ? atoi(getenv("PCRAMP_POST_WAVES")) : 8;
+				if(post_waves == 16) hipLaunchKernelGGL(k_post<16>, dim3((S.n + 15)/16), dim3(1024), 0, ctx->stream, POST_ARGS);
+				else if(post_waves == 4) hipLaunchKernelGGL(k_post<4>, dim3((S.n + 3)/4), dim3(256), 0, ctx->stream, POST_ARGS);
+				else hipLaunchKernelGGL(k_post<8>, dim3((S.n + 7)/8), dim3(512), 0, ctx->stream, POST_ARGS);
 				S.ctrl_clean = true; S.touched_from_seg = true;              // k_post zeroes the counters and fills it has read
 			}
 			else if(cap == 128) hipLaunchKernelGGL((k_post_big<128, 4>), dim3((S.n + 3)/4), dim3(256), 0, ctx->stream, POST_ARGS);
