@@ -989,7 +989,7 @@ int ensure_pos_index(pcr_ctx *ctx, SeqSet &S)
 	{
 		// per 32-base block: its sequence (bit 31: the tile it lies in holds IUPAC codes) and its number within the sequence -- what a
 		// window that reached its floor is asked, in one round trip
-		if(S.n >= (1u << 31)){ return PCR_OK; }
+		if(S.n >= (1u << 30)){ return PCR_OK; }
 		if((rc = S.blk_info.ensure(S.total_blocks + 1)) != PCR_OK) return rc;
 		if((rc = S.blk_local.ensure(S.total_blocks + 1)) != PCR_OK) return rc;
 		std::vector<uint8_t> degen(S.n_tiles + 1, 0);
@@ -1001,7 +1001,7 @@ int ensure_pos_index(pcr_ctx *ctx, SeqSet &S)
 			const uint64_t nt = (S.len[q] >= 32) ? (S.len[q] - 7 + TILE_POS - 1)/TILE_POS : 0;
 			for(uint64_t b = S.blk_off[q];b < S.blk_off[q + 1];++b){
 				const uint64_t bl = b - S.blk_off[q], tile = bl >> 5;                 // 1 024 window starts per tile = 32 blocks
-				info[b] = q | ((tile < nt && degen[t0 + tile]) ? 0x80000000u : 0u);
+				info[b] = q | ((tile < nt && degen[t0 + tile]) ? BLK_DEGEN : 0u) | (S.active[q] ? 0u : BLK_INACTIVE);
 				local[b] = (uint32_t)bl;
 			}
 			t0 += nt;
@@ -1746,6 +1746,10 @@ int pcr_set_active(pcr_ctx *ctx, pcr_set which, const uint8_t *active)
 	if(S.n){
 		HIP_TRY(hipMemcpyAsync(S.d_active.p, S.active.data(), S.n, hipMemcpyHostToDevice, ctx->stream));
 		{ const int rc = build_tile_desc(ctx, S); if(rc != PCR_OK) return rc; }
+		if(S.pix_valid && S.pix_usable && S.total_blocks){                       // the third form reads the flag out of its per-block words
+			hipLaunchKernelGGL(k_blk_active, dim3((unsigned)((S.total_blocks + 255)/256)), dim3(256), 0, ctx->stream, S.blk_info.p, S.blk_seq.p, S.d_active.p, S.total_blocks);
+			HIP_TRY(hipGetLastError());
+		}
 		HIP_TRY(hipStreamSynchronize(ctx->stream));
 	}
 	return PCR_OK;

@@ -44,6 +44,13 @@ def _entries(dev, seqs, pairs, thr, opt5=0, opt3=0, min_len=18):
     return e
 
 
+def _entries_only(dev, pairs, thr, min_len=18):
+    n = dev.select_words(pairs, thr, min_len, 0, 0)
+    e = dev.entries()
+    assert len(e) == n
+    return e
+
+
 def _oracle_entries(oracle, seqs, pairs, thr_t, mult, opt5=0, opt3=0):
     so = oracle.session(target_threshold=thr_t, search_multiplier=mult, amp_min=80, amp_max=200, use_taq_mama=0,
                         pack_max_degen=256, pack_min_gc=0.0, pack_max_gc=1.0, min_primer=18, optimize_5=opt5, optimize_3=opt3)
@@ -302,7 +309,7 @@ def test_three_forms_of_the_seed_pass_agree(oracle, thr_t):
     rng = random.Random(4242)
     seqs, pairs = _border_case(rng, oracle)
     thr = float(np.float32(thr_t) * np.float32(0.9))
-    devs = [api.Screener(0), _screener_env(PCRAMP_SEED3=0), _screener_env(PCRAMP_IRR_INDEX=0)]
+    devs = [api.Screener(0), _screener_env(PCRAMP_SEED3=0), _screener_env(PCRAMP_IRR_INDEX=0), _screener_env(PCRAMP_SCAN=2)]
     try:
         want = _oracle_entries(oracle, seqs, pairs, thr_t, 0.9)
         got = [_entries(d, seqs, pairs, thr) for d in devs]
@@ -311,9 +318,11 @@ def test_three_forms_of_the_seed_pass_agree(oracle, thr_t):
             assert g == want
         # the fused pass (where the third form is the default) after two EOS splits: same bitsets from all three
         outs = []
+        active = np.array([(i % 3) != 1 for i in range(len(seqs))], dtype=np.uint8)     # (the third form keeps the flag in its per-block words)
         for d in devs:
             d.split(len(seqs) - 1, 2500)
             d.split(3, 1030)
+            d.set_active(active)
             words = int(d.bitset_words())
             o = torch.full((2, len(pairs), words), -1, dtype=torch.int64, device="cuda:0")
             for _ in range(3):      # the lean pass starts with the second consecutive fused pass
@@ -321,10 +330,14 @@ def test_three_forms_of_the_seed_pass_agree(oracle, thr_t):
             d.synchronize()
             torch.cuda.synchronize()
             outs.append(o.cpu().numpy().copy())
-        assert np.array_equal(outs[0], outs[1])
-        assert np.array_equal(outs[0], outs[2])
+        for o in outs[1:]:
+            assert np.array_equal(outs[0], o)
         e = [d.entries() for d in devs]
-        assert e[0] == e[1] == e[2] and len(e[0]) > 0
+        assert e[0] == e[1] == e[2] == e[3] and len(e[0]) > 0
+        # ... and all of them active again: the flag is taken back
+        for d in devs:
+            d.set_active(np.ones(len(seqs), np.uint8))
+        assert [_entries_only(d, pairs, thr) for d in devs[1:]] == [_entries_only(devs[0], pairs, thr)] * 3
     finally:
         for d in devs:
             d.close()
