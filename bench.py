@@ -519,7 +519,7 @@ def main():
     ap.add_argument("--no-verify", action="store_true", help="N>1: skip the sharded == unsharded check of the first pass")
     ap.add_argument("--random-primers", action="store_true", help="diagnostic: primers unrelated to the targets (no hits)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--gather-every", type=int, default=16, help="N>1: passes per all-gather (their bitsets travel in one collective)")
+    ap.add_argument("--gather-every", type=int, default=32, help="N>1: passes per all-gather (their bitsets travel in one collective)")
     ap.add_argument("--exchange", choices=["torch", "abi"], default="torch",
                     help="N>1: the all-gather through torch.distributed (async, on RCCL's stream) or through the C-ABI's pcr_exchange_bits "
                          "(ncclAllGather enqueued on the handle's stream; what a C++ host would call)")
