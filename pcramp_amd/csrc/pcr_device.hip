@@ -2190,16 +2190,25 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 	// oligo and floor: between two optimiser iterations most oligos stay what they were).
 	bool want_seed3 = false;
 	if(ctx->scan_version == 3 && !ctx->force_seed1 && !optimize_5 && !optimize_3 && n_or <= 65535 && !ctx->no_seed3 && !ctx->no_irr_index && ctx->s2_dbg == 0){
-		int irc = ensure_pos_index(ctx, S);
-		if(irc != PCR_OK) return irc;
-		uint32_t n_live0 = 0;
-		for(uint32_t k = std::min<uint32_t>(min_oligo_length, 256);k < 256;++k) n_live0 += S.irr_size_count[k];
-		bool irr_ok = n_live0 == 0;
-		if(S.pix_usable && !irr_ok && S.irr_n_multi == 0 && (uint64_t)24*S.n_irr < (uint64_t(1) << 32)){
-			if((irc = ensure_irr_index(ctx, S)) != PCR_OK) return irc;
-			irr_ok = S.irx_usable;
+		// the position index costs 16 bytes per base and milliseconds to build: a set gets it when the first pass that can use it
+		// arrives (every candidate seeded) -- a background set screened at 0.72 never does
+		bool worth = true;
+		if(!S.pix_valid){
+			std::vector<uint32_t> os, op; uint32_t om = 0;
+			worth = plan_seed2(ctx, cand, os, op, om, nullptr) && op.empty() && !os.empty();
 		}
-		want_seed3 = S.pix_usable && irr_ok;
+		if(worth){
+			int irc = ensure_pos_index(ctx, S);
+			if(irc != PCR_OK) return irc;
+			uint32_t n_live0 = 0;
+			for(uint32_t k = std::min<uint32_t>(min_oligo_length, 256);k < 256;++k) n_live0 += S.irr_size_count[k];
+			bool irr_ok = n_live0 == 0;
+			if(S.pix_usable && !irr_ok && S.irr_n_multi == 0 && (uint64_t)24*S.n_irr < (uint64_t(1) << 32)){
+				if((irc = ensure_irr_index(ctx, S)) != PCR_OK) return irc;
+				irr_ok = S.irx_usable;
+			}
+			want_seed3 = S.pix_usable && irr_ok;
+		}
 	}
 	bool use_seed2 = false;
 	if(ctx->scan_version == 3 && !ctx->force_seed1 && !optimize_5 && !optimize_3 && n_or <= 65535){
