@@ -343,6 +343,66 @@ def test_three_forms_of_the_seed_pass_agree(oracle, thr_t):
             d.close()
 
 
+def _random_case(rng, oracle):
+    """A small random screen: a few sequence families (some with IUPAC codes, some with EOS inside), primers cut from them
+    (some mutated, some with IUPAC positions, some unrelated), a select threshold between 0.81 and 1."""
+    seqs = []
+    for _ in range(rng.randint(1, 4)):
+        L = rng.choice((40, 90, 333, 1024, 1500, 2600))
+        root = rand_seq(rng, L, p_degen=rng.choice((0.0, 0.0, 0.002)), p_n=rng.choice((0.0, 0.0, 0.001)))
+        seqs.append(root)
+        for _ in range(rng.randint(0, 6)):
+            m = mutate(rng, root, rng.choice((0.0, 0.01, 0.04)))
+            if rng.random() < 0.15 and L > 200:
+                cut = rng.randrange(50, L - 50)
+                m = m[:cut] + "-" + m[cut + 1:]
+            seqs.append(m[:rng.randint(max(33, L - 40), L)] if rng.random() < 0.3 else m)
+    pairs = []
+    plain = [q for q in seqs if len(q) >= 260]
+    for _ in range(rng.randint(1, 30)):
+        def oligo():
+            n = rng.randint(18, 25)
+            if plain and rng.random() < 0.85:
+                q = rng.choice(plain)
+                a = rng.randrange(0, len(q) - n)
+                o = "".join(c if c in "ACGT" else "A" for c in q[a:a + n])
+                if rng.random() < 0.3:
+                    o = mutate(rng, o, 0.06)
+                if rng.random() < 0.25:
+                    o = list(o)
+                    for _k in range(rng.randint(1, 3)):
+                        o[rng.randrange(n)] = rng.choice("MRSWYKN")
+                    o = "".join(o)
+                return o if rng.random() < 0.5 else revcomp(o)
+            return rand_seq(rng, n)
+        pairs.append((oracle.centered_word(oligo()), oracle.centered_word(oligo())))
+    thr_t = rng.choice((1.0, 1.0, 0.95, 0.9))
+    return seqs, pairs, float(np.float32(thr_t) * np.float32(0.9))
+
+
+def test_random_screens_against_the_bitsliced_scan(both, oracle):
+    """Differential test of the default pass (third form where it applies, the second and first forms elsewhere) against the
+    bit-sliced scan over random small screens, with random inactive sequences and EOS splits (PCRAMP_DIFF_CASES=n for a longer run)."""
+    rng = random.Random(20261005)
+    n_cases = int(os.environ.get("PCRAMP_DIFF_CASES", "200"))
+    nonempty = 0
+    for case in range(n_cases):
+        seqs, pairs, thr = _random_case(rng, oracle)
+        e = [_entries(d, seqs, pairs, thr) for d in both]
+        assert e[0] == e[1], "case %d" % case
+        nonempty += bool(e[0])
+        if rng.random() < 0.5:
+            act = np.array([rng.random() < 0.7 for _ in seqs], dtype=np.uint8)
+            cut = len(seqs[0]) > 200 and rng.random() < 0.5
+            for d in both:
+                d.set_active(act)
+                if cut:
+                    d.split(0, 100)
+            e = [_entries_only(d, pairs, thr) for d in both]
+            assert e[0] == e[1], "case %d (inactive sequences / split)" % case
+    assert nonempty > n_cases // 2
+
+
 def test_lean_passes_leave_a_consistent_state(oracle):
     """From the second fused pass over a set on, the pass is 'lean': no staging launch (tables written into device memory by the
     host, control block left clean by the previous pass's tail, result bitsets cleared by the scan).  Batches that hit different
