@@ -646,7 +646,7 @@ struct SeqSet {
 	DevBuf<uint32_t> irx_first, irx_last, irx_words, irx_sums; bool irx_valid = false, irx_usable = false;   // their inverse index (pcr_scan_seed2.inc), built on demand; usable: no key's run is longer than IRX_MAX_RUN
 	uint32_t irr_n_multi = 0;     // irregular words holding an IUPAC slot (they meet every candidate: no index for them)
 	// the positions of the set by the 9-gram that starts there (pcr_scan_seed3.inc), built on demand after a load
-	DevBuf<uint32_t> pix_first, pix_last, pix_sums, blk_info, blk_local; DevBuf<uint4> pix_ent; std::vector<uint32_t> pix_count_h; uint64_t pix_generation = 0; bool pix_valid = false, pix_usable = false;
+	DevBuf<uint32_t> pix_first, pix_last, pix_sums, blk_info, blk_local, blk_tile0; DevBuf<uint4> pix_ent; std::vector<uint32_t> pix_count_h; uint64_t pix_generation = 0; bool pix_valid = false, pix_usable = false;
 	DevBuf<uint8_t> codes; DevBuf<uint64_t> d_code_off; bool have_codes = false;
 	// word DB of the last select
 	bool have_db = false;
@@ -661,7 +661,7 @@ struct SeqSet {
 	uint32_t *d_seg_hi = nullptr;
 	void release()
 	{
-		d_weight.release(); tile_desc.release(); irr_scan.release(); irx_first.release(); irx_last.release(); irx_words.release(); irx_sums.release(); pix_first.release(); pix_last.release(); pix_ent.release(); pix_sums.release(); blk_info.release(); blk_local.release(); irr_perm.release(); planes.release(); valid.release(); nib.release(); tb.release(); degen_tiles.release(); tile_degen.release(); blk_seq.release(); tile_seq.release(); tile_pos0.release();
+		d_weight.release(); tile_desc.release(); irr_scan.release(); irx_first.release(); irx_last.release(); irx_words.release(); irx_sums.release(); pix_first.release(); pix_last.release(); pix_ent.release(); pix_sums.release(); blk_info.release(); blk_local.release(); blk_tile0.release(); irr_perm.release(); planes.release(); valid.release(); nib.release(); tb.release(); degen_tiles.release(); tile_degen.release(); blk_seq.release(); tile_seq.release(); tile_pos0.release();
 		irr_off.release(); d_len.release(); d_blk_off.release();
 		d_nblk_real.release(); d_active.release(); d_has_eos.release(); irr.release(); db.release(); touched.release(); ctrl.release(); codes.release(); d_code_off.release();
 	}
@@ -992,23 +992,18 @@ int ensure_pos_index(pcr_ctx *ctx, SeqSet &S)
 		if(S.n >= (1u << 30)){ return PCR_OK; }
 		if((rc = S.blk_info.ensure(S.total_blocks + 1)) != PCR_OK) return rc;
 		if((rc = S.blk_local.ensure(S.total_blocks + 1)) != PCR_OK) return rc;
-		std::vector<uint8_t> degen(S.n_tiles + 1, 0);
-		if(S.n_tiles) HIP_TRY(hipMemcpyAsync(degen.data(), S.tile_degen.p, S.n_tiles, hipMemcpyDeviceToHost, ctx->stream));
-		HIP_TRY(hipStreamSynchronize(ctx->stream));
-		std::vector<uint32_t> info(S.total_blocks), local(S.total_blocks);
+		// (made on the device: a C4 shard has 10^8 blocks)
+		std::vector<uint32_t> tile0((size_t)S.n + 1);
 		uint64_t t0 = 0;
-		for(uint32_t q = 0;q < S.n;++q){
-			const uint64_t nt = (S.len[q] >= 32) ? (S.len[q] - 7 + TILE_POS - 1)/TILE_POS : 0;
-			for(uint64_t b = S.blk_off[q];b < S.blk_off[q + 1];++b){
-				const uint64_t bl = b - S.blk_off[q], tile = bl >> 5;                 // 1 024 window starts per tile = 32 blocks
-				info[b] = q | ((tile < nt && degen[t0 + tile]) ? BLK_DEGEN : 0u) | (S.active[q] ? 0u : BLK_INACTIVE);
-				local[b] = (uint32_t)bl;
-			}
-			t0 += nt;
-		}
-		HIP_TRY(hipMemcpyAsync(S.blk_info.p, info.data(), S.total_blocks*sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-		HIP_TRY(hipMemcpyAsync(S.blk_local.p, local.data(), S.total_blocks*sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-		HIP_TRY(hipStreamSynchronize(ctx->stream));
+		for(uint32_t q = 0;q < S.n;++q){ tile0[q] = (uint32_t)t0; t0 += (S.len[q] >= 32) ? (S.len[q] - 7 + TILE_POS - 1)/TILE_POS : 0; }
+		tile0[S.n] = (uint32_t)t0;
+		if(t0 >= (uint64_t(1) << 32)) return PCR_OK;
+		if((rc = S.blk_tile0.ensure((size_t)S.n + 1)) != PCR_OK) return rc;
+		HIP_TRY(hipMemcpyAsync(S.blk_tile0.p, tile0.data(), ((size_t)S.n + 1)*sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+		hipLaunchKernelGGL(k_blk_info, dim3((unsigned)((S.total_blocks + 255)/256)), dim3(256), 0, ctx->stream, S.blk_seq.p, S.d_blk_off.p, S.d_len.p,
+			S.blk_tile0.p, S.tile_degen.p, S.d_active.p, S.total_blocks, S.blk_info.p, S.blk_local.p);
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipStreamSynchronize(ctx->stream));                                  // (tile0 is a local)
 	}
 	HIP_TRY(hipMemsetAsync(S.pix_last.p, 0, (size_t)PIX_CODES*sizeof(uint32_t), ctx->stream));
 	const unsigned grid = (unsigned)((S.total_blocks + 255)/256);
