@@ -729,7 +729,7 @@ struct pcr_ctx {
 		std::vector<uint32_t> chunks; uint32_t chunks_total = 0; uint64_t chunks_gen = 0; /* third form: running 64-entry chunks of the seeds' runs in the set whose position index has this generation */ };
 	std::unordered_map<S2Key, S2Entry, S2KeyHash> s2_cache;
 	std::vector<pcrhost::Seed> s2_tmp;
-	struct S3Launch { Seed3Slices W; uint32_t n_chunks, per_wg, slice_cap; };
+	struct S3Launch { Seed3Slices W; uint32_t n_chunks, per_wg, slice_cap, n_irr_wg; };
 	std::vector<S3Launch> s3_launch;               // third form: per launch group, the workgroups' slices of the chunk list
 	std::vector<uint32_t> s3_prefix; bool no_seed3 = false, s3_attr_set = false;   // third form: the pass's chunk list; PCRAMP_SEED3=0: second form (A/B)
 	bool s2_attr_set = false; uint32_t s2_dbg = 0; bool no_irr_index = false;   // PCRAMP_IRR_INDEX=0: the irregular words scanned in chunks by every wave (A/B)
@@ -1910,9 +1910,10 @@ uint32_t seed3_grid(const pcr_ctx *ctx, int *wg_threads)
 	if(wg_threads) *wg_threads = (s3_wg == 1024) ? 1024 : 512;
 	return std::min<uint32_t>(ctx->n_cu*(uint32_t)(s3_per_cu ? s3_per_cu : (s3_wg == 1024 ? 2 : 4)), S3_MAX_WG);
 }
-bool plan_seed3_slices(pcr_ctx *ctx)
+bool plan_seed3_slices(pcr_ctx *ctx, bool with_irr)
 {
-	const uint32_t G = seed3_grid(ctx, nullptr);
+	int wg_threads = 0;
+	const uint32_t G_all = seed3_grid(ctx, &wg_threads);
 	ctx->s3_launch.resize(ctx->s2_group_end.size());
 	size_t g_begin = 0, g_prefix = 0;
 	for(size_t g = 0;g < ctx->s2_group_end.size();++g){
@@ -1921,6 +1922,10 @@ bool plan_seed3_slices(pcr_ctx *ctx)
 		const uint32_t *P = ctx->s3_prefix.data() + g_prefix;                  // the group's chunk list, [ns + 1]
 		g_prefix += (size_t)ns + 1;
 		pcr_ctx::S3Launch &L = ctx->s3_launch[g];
+		// the launch's first workgroups look the irregular words up (16 seeds per wave turn) and leave the chunks to the others: the two
+		// chains of dependent loads then run side by side; at most a quarter of the launch
+		L.n_irr_wg = with_irr ? std::min<uint32_t>((ns + 16u*(uint32_t)(wg_threads/64) - 1u)/(16u*(uint32_t)(wg_threads/64)), G_all/4u) : 0u;
+		const uint32_t G = G_all - L.n_irr_wg;
 		L.n_chunks = P[ns]; L.per_wg = std::max<uint32_t>(1u, (L.n_chunks + G - 1u)/G); L.slice_cap = 2;
 		if(ns == 0) continue;
 		uint32_t at = 0;
@@ -2183,7 +2188,7 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 	// The second form of the seed scan (pcr_scan_seed2.inc) takes the pass when no 5'/3' shift candidates are asked for and
 	// the orientations and their 9-gram seeds fit its LDS budget; the host then only LISTS the seeds (from a cache keyed by
 	// oligo and floor: between two optimiser iterations most oligos stay what they were).
-	bool want_seed3 = false;
+	bool want_seed3 = false, s3_with_irr = false;       // (the latter: the set has live irregular words, which the third form looks up through their index)
 	if(ctx->scan_version == 3 && !ctx->force_seed1 && !optimize_5 && !optimize_3 && n_or <= 65535 && !ctx->no_seed3 && !ctx->no_irr_index && ctx->s2_dbg == 0){
 		// the position index costs 16 bytes per base and milliseconds to build: a set gets it when the first pass that can use it
 		// arrives (every candidate seeded) -- a background set screened at 0.72 never does
@@ -2202,13 +2207,13 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 				if((irc = ensure_irr_index(ctx, S)) != PCR_OK) return irc;
 				irr_ok = S.irx_usable;
 			}
-			want_seed3 = S.pix_usable && irr_ok;
+			want_seed3 = S.pix_usable && irr_ok; s3_with_irr = n_live0 > 0;
 		}
 	}
 	bool use_seed2 = false;
 	if(ctx->scan_version == 3 && !ctx->force_seed1 && !optimize_5 && !optimize_3 && n_or <= 65535){
 		use_seed2 = plan_seed2(ctx, cand, or_seed, or_plain, irr_off_mask, want_seed3 ? &S : nullptr);
-		if(want_seed3 && !(use_seed2 && or_plain.empty() && !or_seed.empty() && plan_seed3_slices(ctx))){
+		if(want_seed3 && !(use_seed2 && or_plain.empty() && !or_seed.empty() && plan_seed3_slices(ctx, s3_with_irr))){
 			// the third form will not take the pass (an unseeded candidate, or its lists do not fit): plan within the second form's limits
 			or_seed.clear(); or_plain.clear();
 			use_seed2 = plan_seed2(ctx, cand, or_seed, or_plain, irr_off_mask, nullptr);
@@ -2431,6 +2436,7 @@ int select_impl(pcr_ctx *ctx, pcr_set which, const pcr_pair *pairs, uint32_t n_p
 							const uint32_t G = seed3_grid(ctx, &s3_wg);
 							const pcr_ctx::S3Launch &L3 = ctx->s3_launch[g];                   // (plan_seed3_slices)
 							T3.n_chunks = L3.n_chunks; T3.per_wg = L3.per_wg; T3.slice_cap = L3.slice_cap;
+							T3.n_irr_wg = IA.ix_first ? L3.n_irr_wg : 0u;           // (without the index the chunk workgroups are fewer than they could be: harmless)
 							const Seed3Slices &W3 = L3.W;
 							const size_t dyn3 = (size_t)g_or*sizeof(uint4) + 2*(size_t)T3.slice_cap*sizeof(uint32_t) + (((size_t)g_or + 15) & ~size_t(15)) + 16;
 							if(!ctx->s3_attr_set){
